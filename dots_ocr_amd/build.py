@@ -24,7 +24,7 @@ ARCH = "gfx950"
 
 CXXFLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-    "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
     f"-I{INCLUDE}", f"-I{CSRC}",
 ]
 LDFLAGS = ["-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]

@@ -1,0 +1,212 @@
+// Flash attention (prefill) for gfx950: bidirectional var-len (ViT, SURVEY §2.3 V5 — the single
+// biggest cost of a page) and causal GQA (LM prefill, L5).  head_dim = 128, bf16 in/out, fp32
+// softmax and accumulation.  MFMA-bound: 4*n^2*128 flops per (sequence, head).
+//
+// One workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 rows.
+// Everything is computed TRANSPOSED so that all per-row softmax state is lane-local:
+//     S^T[key][q] = K . Q^T      A = K tile (LDS),   B = Q   (registers, loaded once)
+//     O^T[d][q]   = V^T . P^T    A = V^T tile (LDS), B = P^T (registers, straight from S^T)
+// v_mfma_f32_32x32x16_bf16's C layout gives lane (q = l&31, hi = l>>5) the keys
+// {(r&3) + 8(r>>2) + 4hi} of each 32-key tile.  The PV contraction index is free to enumerate keys
+// in any order as long as A and B agree, so instead of shuffling P into "8 consecutive keys per
+// lane" (permlane/bpermute) the V^T buffer is WRITTEN with keys permuted inside each 16-group
+// (0-3, 8-11, 4-7, 12-15; done by qkv_rope_split / elementwise.hip): P^T registers feed the MFMA
+// untouched and V^T fragments are one ds_read_b128 each.
+//
+// LDS: K tile [64 keys][256 B], 16-B slots XOR (key & 15); V^T tile [128 d][128 B], slots XOR
+// ((d >> 1) & 7): both fragment gathers are bank-conflict free.  Double buffered; the next tile is
+// fetched into registers before this tile's MFMAs and written to LDS after them (guide T14),
+// one barrier per tile.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KT_BYTES = 64 * 256;    // K tile
+constexpr int VT_BYTES = 128 * 128;   // V^T tile
+constexpr int BUF_BYTES = KT_BYTES + VT_BYTES;
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
+    bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int64_t T, int64_t Tpad, int Hq, int group,
+    float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+
+    const QBlock qb = blocks[blockIdx.x];
+    const int h = blockIdx.y;
+    const int hkv = h / group;
+    const int tid = threadIdx.x, l = tid & 63, l31 = l & 31, hi = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = qb.n;
+
+    const int qrow = qb.q0 + w * 32 + l31;               // row inside the sequence
+    const int qrow_c = min(qrow, n - 1);
+
+    // ---- Q fragments: B operand, lane (q, hi) holds Q[q][16*ks + 8*hi .. +7] ----
+    bf16x8 qf[8];
+    {
+        const bf16_t* qp = Q + ((size_t)h * T + qb.tok0 + qrow_c) * 128 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    const bf16_t* Kbase = K + ((size_t)hkv * T + qb.tok0) * 128;
+    const bf16_t* Vbase = VT + (size_t)hkv * 128 * Tpad + qb.pad0;
+
+    int n_tiles = (n + 63) >> 6;
+    if (CAUSAL) n_tiles = min(n_tiles, ((qb.q0 + 127) >> 6) + 1);
+
+    // ---- staging (registers): 4 K chunks + 4 V^T chunks of 16 B per thread ----
+    u32x4 kst[4], vst[4];
+    auto stage_load = [&](int j) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid;
+            const int row = min(j * 64 + (item >> 4), n - 1);
+            kst[it] = *reinterpret_cast<const u32x4*>(Kbase + (size_t)row * 128 + (item & 15) * 8);
+            const int d = item >> 3;
+            vst[it] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)d * Tpad + j * 64 + (item & 7) * 8);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* kb = smem + buf * BUF_BYTES;
+        char* vb = kb + KT_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid;
+            const int row = item >> 4, c = item & 15;
+            *reinterpret_cast<u32x4*>(kb + row * 256 + ((c ^ (row & 15)) << 4)) = kst[it];
+            const int d = item >> 3, cv = item & 7;
+            *reinterpret_cast<u32x4*>(vb + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4)) = vst[it];
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    // fragment gather offsets (constant per lane)
+    const int k_row_off = l31 * 256;                 // + kt*32*256
+    const int k_sw = l31 & 15;
+    const int v_row_off = l31 * 128;                 // + dt*32*128
+    const int v_sw = (l31 >> 1) & 7;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int j = 0; j < n_tiles; ++j) {
+        const bool has_next = (j + 1 < n_tiles);
+        if (has_next) stage_load(j + 1);
+        const char* kb = smem + (j & 1) * BUF_BYTES;
+        const char* vb = kb + KT_BYTES;
+
+        // ---- S^T = K . Q^T : 2 key tiles x 8 k-steps ----
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + t * 32 * 256 + k_row_off + (((ks * 2 + hi) ^ k_sw) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+
+        // ---- mask (only the ragged last tile / the causal diagonal) ----
+        const int key0 = j * 64;
+        bool need_mask = (key0 + 64 > n);
+        if (CAUSAL) need_mask = need_mask || (key0 + 63 > qb.q0);
+        if (need_mask) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    bool ok = key < n;
+                    if (CAUSAL) ok = ok && (key <= qrow);
+                    s[t][r] = ok ? s[t][r] : -INFINITY;
+                }
+        }
+
+        // ---- online softmax (per q = lane&31; the two half-waves hold disjoint key subsets) ----
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2e);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float p0 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e], scale_log2e, -m_new));
+                    float p1 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e + 1], scale_log2e, -m_new));
+                    psum += p0 + p1;
+                    pk[e] = pack_bf2(p0, p1);
+                }
+                pf[t * 2 + u] = __builtin_bit_cast(bf16x8, pk);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T : 4 d tiles x 4 key slabs ----
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_row_off + (((sl * 2 + hi) ^ v_sw) << 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sl], o[dt], 0, 0, 0);
+            }
+
+        if (has_next) stage_write((j + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < n) {
+        bf16_t* op = O + ((size_t)(qb.tok0 + qrow) * Hq + h) * 128;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 pk = {pack_bf2(o[dt][4 * rq] * inv, o[dt][4 * rq + 1] * inv),
+                            pack_bf2(o[dt][4 * rq + 2] * inv, o[dt][4 * rq + 3] * inv)};
+                *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * rq + 4 * hi) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+                             const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
+                             int causal, float scale) {
+    if (n_blocks <= 0) return hipSuccess;
+    if (Hq % Hkv != 0) return hipErrorInvalidValue;
+    const float c = scale * 1.44269504088896340736f;
+    dim3 grid(n_blocks, Hq), block(256);
+    if (causal)
+        hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, s, q, k, vt, out, blocks, T, Tpad, Hq, Hq / Hkv, c);
+    else
+        hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, s, q, k, vt, out, blocks, T, Tpad, Hq, Hq / Hkv, c);
+    return hipGetLastError();
+}

@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;      // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;     // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;       // 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define DEVI __device__ __forceinline__
+
+DEVI float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN kept quiet
+DEVI bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+DEVI uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+DEVI float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+DEVI float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+DEVI float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: the dispatcher places block b on XCD b % 8;
+// give every XCD one contiguous chunk of the logical tile order so neighbouring tiles share
+// an L2 (speed only, never correctness).
+DEVI int xcd_remap(int bid, int nblk) {
+    const int NX = 8;
+    int q = nblk / NX, r = nblk % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define HIP_CHECK_RET(expr)                                  \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return _e;                     \
+    } while (0)

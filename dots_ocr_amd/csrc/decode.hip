@@ -1,0 +1,490 @@
+// Decode-step kernels.  One decode step of B <= 16 sequences is HBM-bound:
+// it streams every LM weight once (3.09 GB bf16) plus ctx*28 672 B of KV per sequence.
+//
+// Paged KV cache, pages of 64 tokens, stored in MFMA-FRAGMENT ORDER so that every wave-level load
+// in decode attention is one fully contiguous 1 KiB global_load_dwordx4 that lands directly in the
+// v_mfma_f32_16x16x32_bf16 A-operand registers (no LDS, no shuffles):
+//   pool[layer][page][kv_head][0 = K | 1 = V][8192 bf16]
+//   K (key, d):  chunk ((key>>4)*4 + (d>>5))*64 + ((d>>3)&3)*16 + (key&15),  element d&7
+//                -> chunk (kg,kk), lane (g,i) = K[16kg+i][32kk+8g .. +7]       (A of S^T = K.Q^T)
+//   V (key, d):  chunk ((key>>5)*8 + (d>>4))*64 + (((key&31)>>2)&3)*16 + (d&15), element 4*((key&31)>>4) + (key&3)
+//                -> chunk (slab,dg), lane (g,i) = V^T[16dg+i][keys 32slab + {4g..4g+3, 16+4g..16+4g+3}]
+//                   which is exactly the key order in which a lane holds P^T after the S^T MFMAs
+//                   (A of O^T = V^T.P^T).
+//
+// Dense layers at M = B <= 16 rows: skinny split-K GEMM on MFMA with the weight tile as the A operand,
+// weights streamed straight to VGPRs in 64-B-per-lane runs (guide: "GEMV / M<=16: neither LDS nor glds"),
+// fp32 partial slabs reduced deterministically (fixed order, no atomics) inside the next fused kernel.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int PAGE = 64;
+constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
+
+DEVI int k_chunk(int key, int d) { return ((key >> 4) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (key & 15); }
+DEVI int v_off(int key, int d) {
+    const int kk = key & 31;
+    return (((key >> 5) * 8 + (d >> 4)) * 64 + ((kk >> 2) & 3) * 16 + (d & 15)) * 8 + 4 * (kk >> 4) + (kk & 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefill -> pages.  grid (tiles, Hkv, 2); K from the rope'd head-major buffer, V from the qkv buffer.
+__global__ __launch_bounds__(256) void kv_to_pages_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ qkv,
+                                                          const Tile64* __restrict__ tiles, const int32_t* __restrict__ block_table,
+                                                          int max_pages, bf16_t* __restrict__ pool, int64_t T, int Hq, int Hkv) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[64 * 136];
+    const Tile64 tl = tiles[blockIdx.x];
+    const int h = blockIdx.y, which = blockIdx.z, tid = threadIdx.x;
+    const int page = block_table[tl.seq * max_pages + tl.page];
+    bf16_t* dst = pool + ((size_t)(page * Hkv + h) * 2 + which) * PAGE_ELEMS;
+    if (which == 0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ci = it * 256 + tid;                       // destination chunk
+            const int i = ci & 15, g = (ci >> 4) & 3, kk = (ci >> 6) & 3, kg = ci >> 8;
+            const int key = kg * 16 + i;
+            u32x4 v = {0, 0, 0, 0};
+            if (key < tl.n) v = *reinterpret_cast<const u32x4*>(k + ((size_t)h * T + tl.tok0 + key) * 128 + kk * 32 + g * 8);
+            *reinterpret_cast<u32x4*>(dst + (size_t)ci * 8) = v;
+        }
+    } else {
+        const int ld = (Hq + 2 * Hkv) * 128;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid;
+            const int tok = item >> 4, c = item & 15;
+            u32x4 v = {0, 0, 0, 0};
+            if (tok < tl.n) v = *reinterpret_cast<const u32x4*>(qkv + (size_t)(tl.tok0 + tok) * ld + (Hq + Hkv + h) * 128 + c * 8);
+            *reinterpret_cast<u32x4*>(&lds[tok * 136 + c * 8]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ci = it * 256 + tid;
+            const int i = ci & 15, g = (ci >> 4) & 3, dg = (ci >> 6) & 7, slab = ci >> 9;
+            const int d = dg * 16 + i;
+            u32x4 o;
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const int e0 = 2 * e2, e1 = 2 * e2 + 1;
+                const int key0 = slab * 32 + (e0 >> 2) * 16 + g * 4 + (e0 & 3);
+                const int key1 = slab * 32 + (e1 >> 2) * 16 + g * 4 + (e1 & 3);
+                o[e2] = (uint32_t)lds[key0 * 136 + d] | ((uint32_t)lds[key1 * 136 + d] << 16);
+            }
+            *reinterpret_cast<u32x4*>(dst + (size_t)ci * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM: partial[s][m][n] = sum over K-slice s of X[m][k] * W[n][k], m < 16.
+// grid (N/64, S); wave = one 16-row weight tile; per 128-k group a lane reads 64 contiguous bytes of
+// its weight row as 4 x 16 B (MFMA j takes bytes 16j..16j+15 of every lane's run: the contraction
+// order inside the group is permuted identically for W and X, which a dot product does not care about).
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                          float* __restrict__ partial, int N, int K, int S) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = l & 15, g = l >> 4;
+    const int n0 = (blockIdx.x * 4 + w) * 16;
+    if (n0 >= N) return;
+    const int ngroups = K / 128;
+    const int s = blockIdx.y;
+    const int g0 = (int)((int64_t)s * ngroups / S), g1 = (int)((int64_t)(s + 1) * ngroups / S);
+    const bf16_t* wp = W + (size_t)(n0 + i) * K + g * 32;
+    const bf16_t* xp = X + (size_t)i * K + g * 32;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int kg = g0;
+    for (; kg + 1 < g1; kg += 2) {
+        bf16x8 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)kg * 128 + j * 8));
+            a[4 + j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)(kg + 1) * 128 + j * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)kg * 128 + j * 8);
+            b[4 + j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)(kg + 1) * 128 + j * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4 + j], b[4 + j], acc1, 0, 0, 0);
+        }
+    }
+    if (kg < g1) {
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)kg * 128 + j * 8));
+            b[j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)kg * 128 + j * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
+    }
+    // D[n = 4g + r][m = i]  ->  partial[s][m][n0 + 4g .. +3]
+    f32x4 r = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
+    *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;
+}
+
+__global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                  int N, int S) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)16 * N) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += partial[(size_t)s * 16 * N + idx];
+    out[idx] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// h[b] = embed[tok[b]];  xn[b] = rmsnorm(h[b]) * w      (grid B, block 256)
+DEVI float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ embed,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ h,
+                                                            bf16_t* __restrict__ xn, int dim, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const bf16_t* src = embed + (size_t)tokens[b] * dim;
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        const bf16_t v = src[d];
+        h[(size_t)b * dim + d] = v;
+        const float f = bf2f(v);
+        ss += f * f;
+    }
+    const float rstd = rsqrtf(block_sum_256(ss, red) / dim + eps);
+    for (int d = threadIdx.x; d < dim; d += 256)
+        xn[(size_t)b * dim + d] = f2bf(bf2f(f2bf(bf2f(src[d]) * rstd)) * bf2f(w[d]));
+}
+
+// h[b] = bf16(h[b] + sum_s partial[s][b][:]);  xn[b] = rmsnorm(h[b]) * w
+__global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ h,
+                                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
+                                                                      int dim, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float vals[8];
+    float ss = 0.f;
+    int c = 0;
+    for (int d = threadIdx.x; d < dim; d += 256, ++c) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += partial[((size_t)s * 16 + b) * dim + d];
+        const bf16_t hv = f2bf(bf2f(h[(size_t)b * dim + d]) + a);
+        h[(size_t)b * dim + d] = hv;
+        const float f = bf2f(hv);
+        vals[c] = f;
+        ss += f * f;
+    }
+    const float rstd = rsqrtf(block_sum_256(ss, red) / dim + eps);
+    c = 0;
+    for (int d = threadIdx.x; d < dim; d += 256, ++c)
+        xn[(size_t)b * dim + d] = f2bf(bf2f(f2bf(vals[c] * rstd)) * bf2f(w[d]));
+}
+
+// act[b][j] = silu(sum_s P[s][b][gate(j)]) * sum_s P[s][b][up(j)], packed rows: group of 64 = 32 gate | 32 up
+__global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ act,
+                                                            int I, int B) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * I) return;
+    const int b = idx / I, j = idx - b * I;
+    const int ng = (j >> 5) * 64 + (j & 31);
+    float gsum = 0.f, usum = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* p = partial + ((size_t)s * 16 + b) * (2 * I);
+        gsum += p[ng];
+        usum += p[ng + 32];
+    }
+    act[(size_t)b * I + j] = f2bf(gsum / (1.0f + __expf(-gsum)) * usum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// qkv partials -> (+bias) -> rope at pos = ctx_len[b] -> q_out[b][Hq*128] bf16, K/V appended to the page.
+__global__ __launch_bounds__(256) void qkv_post_decode_kernel(const float* __restrict__ partial, int S, const bf16_t* __restrict__ bias,
+                                                              const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
+                                                              const int32_t* __restrict__ block_table, int max_pages,
+                                                              bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out, int Hq, int Hkv) {
+    const int b = blockIdx.x;
+    const int Nq = (Hq + 2 * Hkv) * 128;
+    const int pos = ctx_len[b];
+    const int page = block_table[b * max_pages + (pos >> 6)];
+    const int key = pos & 63;
+    auto val = [&](int n) {
+        float a = bias ? bf2f(bias[n]) : 0.f;
+        for (int s = 0; s < S; ++s) a += partial[((size_t)s * 16 + b) * Nq + n];
+        return bf2f(f2bf(a));          // the qkv projection output is a bf16 tensor
+    };
+    // rope pairs (d, d+64) of the q and k heads
+    for (int item = threadIdx.x; item < (Hq + Hkv) * 64; item += 256) {
+        const int head = item >> 6, d = item & 63;
+        const float x1 = val(head * 128 + d), x2 = val(head * 128 + d + 64);
+        float sn, cs;
+        sincosf((float)pos * inv_freq[d], &sn, &cs);
+        const bf16_t o1 = f2bf(x1 * cs - x2 * sn), o2 = f2bf(x2 * cs + x1 * sn);
+        if (head < Hq) {
+            q_out[(size_t)b * Hq * 128 + head * 128 + d] = o1;
+            q_out[(size_t)b * Hq * 128 + head * 128 + d + 64] = o2;
+        } else {
+            bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
+            kp[k_chunk(key, d) * 8 + (d & 7)] = o1;
+            kp[k_chunk(key, d + 64) * 8 + (d & 7)] = o2;
+        }
+    }
+    for (int item = threadIdx.x; item < Hkv * 128; item += 256) {
+        const int head = item >> 7, d = item & 127;
+        bf16_t* vp = pool + ((size_t)(page * Hkv + head) * 2 + 1) * PAGE_ELEMS;
+        vp[v_off(key, d)] = f2bf(val((Hq + Hkv + head) * 128 + d));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-KV decode attention.  grid (n_splits, Hkv, B), 4 waves; wave w walks pages split*4 + w,
+// += 4*n_splits.  All `group` (<= 16) query heads of one kv head share every K/V load (GQA).
+// Output per (b, hkv, split): unnormalised O [group][128] fp32, (m, l) [group].
+__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
+                                                          const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
+                                                          int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                          int Hq, int Hkv, int n_splits, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) float lds_o[4][16 * 128];
+    __shared__ float lds_m[4][16], lds_l[4][16];
+    const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+    const int group = Hq / Hkv;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
+    const int ctx = ctx_len[b] + 1;                       // includes the token appended this step
+    const int n_pages = (ctx + PAGE - 1) / PAGE;
+
+    // Q fragments (B operand): lane (j = i, g) holds Q[hkv*group + j][32kk + 8g .. +7]; zero rows j >= group
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        u32x4 z = {0, 0, 0, 0};
+        if (i < group) z = *reinterpret_cast<const u32x4*>(q + ((size_t)b * Hq + hkv * group + i) * 128 + kk * 32 + g * 8);
+        qf[kk] = __builtin_bit_cast(bf16x8, z);
+    }
+    f32x4 o[8];
+#pragma unroll
+    for (int dg = 0; dg < 8; ++dg) o[dg] = f32x4{0, 0, 0, 0};
+    float m_run = -1e30f, l_run = 0.f;
+
+    for (int p = split * 4 + w; p < n_pages; p += 4 * n_splits) {
+        const int page = block_table[b * max_pages + p];
+        const bf16_t* kp = pool + ((size_t)(page * Hkv + hkv) * 2) * PAGE_ELEMS;
+        const bf16_t* vp = kp + PAGE_ELEMS;
+        bf16x8 kf[16], vf[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) kf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kp + (size_t)(c * 64 + l) * 8));
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vp + (size_t)(c * 64 + l) * 8));
+        // S^T[kg] : rows = keys 16kg + 4g + r, col = q head i
+        f32x4 s[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            s[kg] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[kg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kg * 4 + kk], qf[kk], s[kg], 0, 0, 0);
+        }
+        const int key0 = p * PAGE;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + kg * 16 + 4 * g + r;
+                s[kg][r] = key < ctx ? s[kg][r] : -INFINITY;
+                mx = fmaxf(mx, s[kg][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2e);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            u32x4 pk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(fmaf(s[slab * 2 + t][r], scale_log2e, -m_new));
+                    psum += pv[r];
+                }
+                pk[t * 2] = pack_bf2(pv[0], pv[1]);
+                pk[t * 2 + 1] = pack_bf2(pv[2], pv[3]);
+            }
+            pf[slab] = __builtin_bit_cast(bf16x8, pk);
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dg = 0; dg < 8; ++dg) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dg][r] *= alpha;
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab)
+                o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[slab * 8 + dg], pf[slab], o[dg], 0, 0, 0);
+        }
+    }
+    // wave partial: l over the 4 lane groups that share a q column
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (g == 0) { lds_m[w][i] = m_run; lds_l[w][i] = l_run; }
+#pragma unroll
+    for (int dg = 0; dg < 8; ++dg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_o[w][i * 128 + dg * 16 + 4 * g + r] = o[dg][r];     // O^T[d = 16dg+4g+r][q = i]
+    __syncthreads();
+    // combine the 4 waves: thread -> (q head j, d) pairs
+    for (int item = threadIdx.x; item < group * 128; item += 256) {
+        const int j = item >> 7, d = item & 127;
+        float m = fmaxf(fmaxf(lds_m[0][j], lds_m[1][j]), fmaxf(lds_m[2][j], lds_m[3][j]));
+        float acc = 0.f, lsum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float f = __builtin_amdgcn_exp2f(lds_m[ww][j] - m);
+            acc += lds_o[ww][j * 128 + d] * f;
+            lsum += lds_l[ww][j] * f;
+        }
+        const size_t base = (((size_t)b * Hkv + hkv) * n_splits + split) * group + j;
+        part_o[base * 128 + d] = acc;
+        if (d == 0) { part_ml[base * 2] = m; part_ml[base * 2 + 1] = lsum; }
+    }
+}
+
+// out[b][head*128 + d] = sum_s w_s O_s / sum_s w_s l_s   (grid (Hq, B), block 128)
+__global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                  bf16_t* __restrict__ out, int Hq, int Hkv, int n_splits) {
+    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const int group = Hq / Hkv, hkv = head / group, j = head % group;
+    float m = -1e30f;
+    for (int s = 0; s < n_splits; ++s) m = fmaxf(m, part_ml[((((size_t)b * Hkv + hkv) * n_splits + s) * group + j) * 2]);
+    float acc = 0.f, lsum = 0.f;
+    for (int s = 0; s < n_splits; ++s) {
+        const size_t base = (((size_t)b * Hkv + hkv) * n_splits + s) * group + j;
+        const float f = __builtin_amdgcn_exp2f(part_ml[base * 2] - m);
+        acc += part_o[base * 128 + d] * f;
+        lsum += part_ml[base * 2 + 1] * f;
+    }
+    out[((size_t)b * Hq + head) * 128 + d] = f2bf(acc / lsum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy step glue: argmax (first index wins ties, like torch.argmax), EOS / length bookkeeping.
+__global__ __launch_bounds__(1024) void argmax_step_kernel(const float* __restrict__ logits, int V, int ld, int32_t* __restrict__ cur_tokens,
+                                                           int32_t* __restrict__ ctx_len, int32_t* __restrict__ out_ids,
+                                                           int32_t* __restrict__ out_lens, int32_t* __restrict__ finished,
+                                                           const int32_t* __restrict__ eos_ids, int n_eos, int max_new_tokens,
+                                                           int advance_ctx, const int32_t* __restrict__ forced) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x;
+    const float* row = logits + (size_t)b * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 1024) {
+        const float v = row[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        if (advance_ctx) ctx_len[b] += 1;
+        if (!finished[b]) {
+            const int n = out_lens[b];
+            out_ids[(size_t)b * max_new_tokens + n] = bi;
+            out_lens[b] = n + 1;
+            bool eos = false;
+            for (int k = 0; k < n_eos; ++k) eos = eos || (bi == eos_ids[k]);
+            if (eos || n + 1 >= max_new_tokens) finished[b] = 1;
+        }
+        cur_tokens[b] = (forced && forced[b] >= 0) ? forced[b] : bi;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
+                              const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv) {
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kv_to_pages_kernel, dim3(n_tiles, Hkv, 2), dim3(256), 0, s, k, qkv, tiles, block_table, max_pages,
+                       pool_layer, T, Hq, Hkv);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* X, const bf16_t* W, float* partial, int N, int K, int splitk) {
+    if (N % 16 != 0 || K % 128 != 0 || splitk < 1 || splitk > K / 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 63) / 64, splitk), dim3(256), 0, s, X, W, partial, N, K, splitk);
+    return hipGetLastError();
+}
+
+hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk) {
+    hipLaunchKernelGGL(skinny_reduce_plain_kernel, dim3((16 * N + 255) / 256), dim3(256), 0, s, partial, out, N, splitk);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
+                                bf16_t* h, bf16_t* xn, int B, int dim, float eps) {
+    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(B), dim3(256), 0, s, tokens, embed, w, h, xn, dim, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
+                                          bf16_t* xn, int B, int dim, float eps) {
+    if (dim > 8 * 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_residual_rmsnorm_kernel, dim3(B), dim3(256), 0, s, partial, splitk, h, w, xn, dim, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B) {
+    hipLaunchKernelGGL(reduce_swiglu_kernel, dim3((B * I + 255) / 256), dim3(256), 0, s, partial, splitk, act, I, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
+                                  const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
+                                  int max_pages, bf16_t* pool_layer, bf16_t* q_out, int B, int Hq, int Hkv) {
+    hipLaunchKernelGGL(qkv_post_decode_kernel, dim3(B), dim3(256), 0, s, partial, splitk, bias, inv_freq, ctx_len, block_table,
+                       max_pages, pool_layer, q_out, Hq, Hkv);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
+                              const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
+                              int B, int Hq, int Hkv, int n_splits, float scale) {
+    if (Hq % Hkv != 0 || Hq / Hkv > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(n_splits, Hkv, B), dim3(256), 0, s, q, pool_layer, ctx_len, block_table,
+                       max_pages, part_o, part_ml, Hq, Hkv, n_splits, scale * 1.44269504088896340736f);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
+                                      int B, int Hq, int Hkv, int n_splits) {
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, out, Hq, Hkv, n_splits);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, int32_t* cur_tokens, int32_t* ctx_len,
+                              int32_t* out_ids, int32_t* out_lens, int32_t* finished, const int32_t* eos_ids, int n_eos,
+                              int max_new_tokens, int advance_ctx, const int32_t* forced) {
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(1024), 0, s, logits, V, ld, cur_tokens, ctx_len, out_ids, out_lens,
+                       finished, eos_ids, n_eos, max_new_tokens, advance_ctx, forced);
+    return hipGetLastError();
+}

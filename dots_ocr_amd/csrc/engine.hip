@@ -1,0 +1,1009 @@
+// Host orchestration + C ABI of the dots.ocr engine (include/dots_ocr_hip.h).
+//
+// One DotsEngine = one GPU = one HIP stream.  It owns the bf16 weights (packed once at
+// dots_finalize_weights), the ViT / prefill workspaces, the paged KV pool and the decode buffers.
+// The decode step is captured once per dots_generate call into a hipGraph and replayed: every
+// per-step quantity (token ids, context lengths, block tables) lives in device memory and is read
+// through pointers, so the graph never needs parameter updates (SURVEY §7 "hard parts").
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "dots_ocr_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+    bf16_t* p = nullptr;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct VLayer { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *w13, *b13, *w2, *b2; };
+struct LLayer { bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *w13, *down_w; };
+
+__global__ void pack_w13_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up, bf16_t* __restrict__ out, int I, int K) {
+    // out row r: group G = r/64; rows [0,32) of the group = gate[G*32 ..], rows [32,64) = up[G*32 ..]
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-B chunk index
+    const int cpr = K / 8;
+    if (idx >= (int64_t)2 * I * cpr) return;
+    const int r = (int)(idx / cpr), c = (int)(idx % cpr);
+    const int G = r >> 6, wi = r & 63;
+    const bf16_t* src = (wi < 32 ? gate + (size_t)(G * 32 + wi) * K : up + (size_t)(G * 32 + wi - 32) * K) + c * 8;
+    *reinterpret_cast<u32x4*>(out + (size_t)r * K + c * 8) = *reinterpret_cast<const u32x4*>(src);
+}
+
+__global__ void pack_b13_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up, bf16_t* __restrict__ out, int I) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * I) return;
+    const int G = r >> 6, wi = r & 63;
+    out[r] = wi < 32 ? gate[G * 32 + wi] : up[G * 32 + wi - 32];
+}
+
+__global__ void convert_kernel(const void* __restrict__ src, int dtype, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (dtype == DOTS_DTYPE_F32) dst[i] = f2bf(reinterpret_cast<const float*>(src)[i]);
+    else if (dtype == DOTS_DTYPE_F16) dst[i] = f2bf(__half2float(reinterpret_cast<const __half*>(src)[i]));
+    else dst[i] = reinterpret_cast<const bf16_t*>(src)[i];
+}
+
+// rows [n, K] -> [n, Kpad] zero padded
+__global__ void pad_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n, int K, int Kpad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * Kpad) return;
+    const int r = (int)(i / Kpad), c = (int)(i % Kpad);
+    dst[i] = c < K ? src[(size_t)r * K + c] : (bf16_t)0;
+}
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K) {
+    const int64_t n = (int64_t)2 * I * (K / 8);
+    hipLaunchKernelGGL(pack_w13_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gate, up, out, I, K);
+    return hipGetLastError();
+}
+hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n) {
+    hipLaunchKernelGGL(convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dtype, dst, n);
+    return hipGetLastError();
+}
+
+struct DotsEngine {
+    DotsConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    bool finalized = false;
+
+    std::unordered_map<std::string, Tensor> raw;     // checkpoint tensors as loaded (bf16, device)
+
+    // packed weights
+    bf16_t *patch_w = nullptr, *patch_b = nullptr, *patch_norm = nullptr;
+    int patch_k = 0, patch_kpad = 0;
+    std::vector<VLayer> vl;
+    bf16_t *v_post_norm = nullptr, *m_ln_w = nullptr, *m_ln_b = nullptr, *m0_w = nullptr, *m0_b = nullptr, *m2_w = nullptr, *m2_b = nullptr;
+    bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
+    std::vector<LLayer> ll;
+    float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
+
+    // ---- ViT workspace (max_patches rows)
+    int64_t P = 0, Ppad = 0;
+    bf16_t *v_xa = nullptr, *v_x = nullptr, *v_xn = nullptr, *v_qkv = nullptr, *v_q = nullptr, *v_k = nullptr, *v_vt = nullptr,
+           *v_att = nullptr, *v_act = nullptr, *v_mh = nullptr, *vis = nullptr;
+    float* v_pix = nullptr;
+    float2* v_cs = nullptr;
+    int32_t* v_pos = nullptr;
+    Tile64* v_tiles = nullptr;
+    QBlock* v_qblocks = nullptr;
+    int64_t vis_rows = 0;
+    std::vector<int32_t> h_pos;
+    std::vector<Tile64> h_tiles;
+    std::vector<QBlock> h_qblocks;
+
+    // ---- prefill workspace (max_prefill_tokens rows)
+    int64_t TP = 0, TPpad = 0;
+    bf16_t *p_x = nullptr, *p_xn = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_k = nullptr, *p_vt = nullptr, *p_att = nullptr, *p_act = nullptr;
+    float2* p_cs = nullptr;
+    int32_t *p_pos = nullptr, *p_src = nullptr, *p_last = nullptr;
+    Tile64* p_tiles = nullptr;
+    QBlock* p_qblocks = nullptr;
+    std::vector<int32_t> hp_pos, hp_src, hp_last, hp_table;
+    std::vector<Tile64> hp_tiles;
+    std::vector<QBlock> hp_qblocks;
+
+    // ---- KV pool + decode state
+    int max_pages = 0;                     // per sequence
+    bf16_t* pool = nullptr;                // [layers][max_batch*max_pages][Hkv][2][8192]
+    size_t pool_layer_elems = 0;
+    int32_t *block_table = nullptr, *ctx_len = nullptr, *cur_tokens = nullptr, *out_ids = nullptr, *out_lens = nullptr,
+            *finished = nullptr, *eos_ids = nullptr, *forced = nullptr;
+    int n_eos = 0;
+    int out_cap = 0;                       // row stride of out_ids for the current generation
+    bf16_t *d_h = nullptr, *d_xn = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
+    float *d_partial = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
+    int B = 0;                             // sequences of the current batch
+    std::vector<int> h_prompt_lens;
+    int steps_done = 0;
+
+    // ---- timing
+    hipEvent_t ev[8]{};
+    std::vector<hipEvent_t> attn_ev;
+    DotsStats stats{};
+    int attn_pairs = 0;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    template <typename T>
+    hipError_t alloc(T** p, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 256));
+        if (e != hipSuccess) return e;
+        allocs.push_back(q);
+        *p = reinterpret_cast<T*>(q);
+        return hipMemsetAsync(q, 0, std::max<size_t>(count * sizeof(T), 256), stream);
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = std::find(allocs.begin(), allocs.end(), p);
+        if (it != allocs.end()) allocs.erase(it);
+        hipFree(p);
+    }
+};
+
+#define CK(expr)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return e->fail(DOTS_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+int skinny_splits(int N, int K) {
+    const int blocks = (N + 63) / 64;
+    int s = (512 + blocks / 2) / blocks;
+    s = std::max(1, std::min(s, std::min(K / 128, 16)));
+    return s;
+}
+
+// ---------------------------------------------------------------------------------- weights
+const Tensor* find(DotsEngine* e, const std::string& name) {
+    auto it = e->raw.find(name);
+    return it == e->raw.end() ? nullptr : &it->second;
+}
+
+int need(DotsEngine* e, const std::string& name, std::initializer_list<int64_t> shape, bf16_t** out) {
+    const Tensor* t = find(e, name);
+    if (!t) return e->fail(DOTS_E_STATE, "missing weight %s", name.c_str());
+    if (t->shape != std::vector<int64_t>(shape)) return e->fail(DOTS_E_INVALID, "weight %s has unexpected shape", name.c_str());
+    *out = t->p;
+    return DOTS_OK;
+}
+
+int optional(DotsEngine* e, const std::string& name, std::initializer_list<int64_t> shape, bf16_t** out) {
+    const Tensor* t = find(e, name);
+    *out = nullptr;
+    if (!t) return DOTS_OK;
+    if (t->shape != std::vector<int64_t>(shape)) return e->fail(DOTS_E_INVALID, "weight %s has unexpected shape", name.c_str());
+    *out = t->p;
+    return DOTS_OK;
+}
+
+void drop(DotsEngine* e, const std::string& name) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end()) return;
+    e->release(it->second.p);
+    e->raw.erase(it);
+}
+
+#define RET(x) do { int r_ = (x); if (r_ != DOTS_OK) return r_; } while (0)
+
+int finalize_weights(DotsEngine* e) {
+    const DotsConfig& c = e->cfg;
+    hipStream_t s = e->stream;
+    const int E = c.v_embed_dim, Iv = c.v_intermediate;
+    // ---- vision
+    {
+        const std::string pre = "vision_tower.patch_embed.patchifier.";
+        const Tensor* pw = find(e, pre + "proj.weight");
+        if (!pw) return e->fail(DOTS_E_STATE, "missing weight %sproj.weight", pre.c_str());
+        const int K = c.v_channels * c.v_patch * c.v_patch;
+        if (pw->numel() != (int64_t)E * K) return e->fail(DOTS_E_INVALID, "patch embed weight has unexpected size");
+        e->patch_k = K;
+        e->patch_kpad = (int)round_up(K, 64);
+        CK(e->alloc(&e->patch_w, (size_t)E * e->patch_kpad));
+        const int64_t n = (int64_t)E * e->patch_kpad;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pw->p, e->patch_w, E, K, e->patch_kpad);
+        RET(optional(e, pre + "proj.bias", {E}, &e->patch_b));
+        RET(need(e, pre + "norm.weight", {E}, &e->patch_norm));
+    }
+    e->vl.resize(c.v_layers);
+    for (int i = 0; i < c.v_layers; ++i) {
+        const std::string p = "vision_tower.blocks." + std::to_string(i) + ".";
+        VLayer& L = e->vl[i];
+        RET(need(e, p + "norm1.weight", {E}, &L.norm1));
+        RET(need(e, p + "attn.qkv.weight", {3 * E, E}, &L.qkv_w));
+        RET(optional(e, p + "attn.qkv.bias", {3 * E}, &L.qkv_b));
+        RET(need(e, p + "attn.proj.weight", {E, E}, &L.proj_w));
+        RET(optional(e, p + "attn.proj.bias", {E}, &L.proj_b));
+        RET(need(e, p + "norm2.weight", {E}, &L.norm2));
+        bf16_t *f1, *f3, *b1, *b3;
+        RET(need(e, p + "mlp.fc1.weight", {Iv, E}, &f1));
+        RET(need(e, p + "mlp.fc3.weight", {Iv, E}, &f3));
+        RET(need(e, p + "mlp.fc2.weight", {E, Iv}, &L.w2));
+        RET(optional(e, p + "mlp.fc1.bias", {Iv}, &b1));
+        RET(optional(e, p + "mlp.fc3.bias", {Iv}, &b3));
+        RET(optional(e, p + "mlp.fc2.bias", {E}, &L.b2));
+        CK(e->alloc(&L.w13, (size_t)2 * Iv * E));
+        CK(launch_pack_w13(s, f1, f3, L.w13, Iv, E));
+        L.b13 = nullptr;
+        if (b1 && b3) {
+            CK(e->alloc(&L.b13, (size_t)2 * Iv));
+            hipLaunchKernelGGL(pack_b13_kernel, dim3((2 * Iv + 255) / 256), dim3(256), 0, s, b1, b3, L.b13, Iv);
+        }
+        CK(hipStreamSynchronize(s));
+        drop(e, p + "mlp.fc1.weight");
+        drop(e, p + "mlp.fc3.weight");
+    }
+    if (c.v_post_norm) RET(need(e, "vision_tower.post_trunk_norm.weight", {E}, &e->v_post_norm));
+    const int Mg = E * c.v_merge * c.v_merge;
+    RET(need(e, "vision_tower.merger.ln_q.weight", {E}, &e->m_ln_w));
+    RET(need(e, "vision_tower.merger.ln_q.bias", {E}, &e->m_ln_b));
+    RET(need(e, "vision_tower.merger.mlp.0.weight", {Mg, Mg}, &e->m0_w));
+    RET(need(e, "vision_tower.merger.mlp.0.bias", {Mg}, &e->m0_b));
+    RET(need(e, "vision_tower.merger.mlp.2.weight", {c.hidden_size, Mg}, &e->m2_w));
+    RET(need(e, "vision_tower.merger.mlp.2.bias", {c.hidden_size}, &e->m2_b));
+
+    // ---- language model
+    const int H = c.hidden_size, I = c.intermediate_size, Nq = c.num_heads * 128, Nkv = c.num_kv_heads * 128;
+    RET(need(e, "model.embed_tokens.weight", {c.vocab_size, H}, &e->embed));
+    RET(need(e, "model.norm.weight", {H}, &e->final_norm));
+    if (find(e, "lm_head.weight")) RET(need(e, "lm_head.weight", {c.vocab_size, H}, &e->lm_head));
+    else e->lm_head = e->embed;                      // tie_word_embeddings
+    e->ll.resize(c.num_layers);
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        LLayer& L = e->ll[i];
+        RET(need(e, p + "input_layernorm.weight", {H}, &L.ln1));
+        RET(need(e, p + "post_attention_layernorm.weight", {H}, &L.ln2));
+        bf16_t *qw, *kw, *vw, *qb, *kb, *vb, *gw, *uw;
+        RET(need(e, p + "self_attn.q_proj.weight", {Nq, H}, &qw));
+        RET(need(e, p + "self_attn.k_proj.weight", {Nkv, H}, &kw));
+        RET(need(e, p + "self_attn.v_proj.weight", {Nkv, H}, &vw));
+        RET(optional(e, p + "self_attn.q_proj.bias", {Nq}, &qb));
+        RET(optional(e, p + "self_attn.k_proj.bias", {Nkv}, &kb));
+        RET(optional(e, p + "self_attn.v_proj.bias", {Nkv}, &vb));
+        RET(need(e, p + "self_attn.o_proj.weight", {H, Nq}, &L.o_w));
+        RET(need(e, p + "mlp.gate_proj.weight", {I, H}, &gw));
+        RET(need(e, p + "mlp.up_proj.weight", {I, H}, &uw));
+        RET(need(e, p + "mlp.down_proj.weight", {H, I}, &L.down_w));
+        CK(e->alloc(&L.qkv_w, (size_t)(Nq + 2 * Nkv) * H));
+        CK(hipMemcpyAsync(L.qkv_w, qw, (size_t)Nq * H * 2, hipMemcpyDeviceToDevice, s));
+        CK(hipMemcpyAsync(L.qkv_w + (size_t)Nq * H, kw, (size_t)Nkv * H * 2, hipMemcpyDeviceToDevice, s));
+        CK(hipMemcpyAsync(L.qkv_w + (size_t)(Nq + Nkv) * H, vw, (size_t)Nkv * H * 2, hipMemcpyDeviceToDevice, s));
+        L.qkv_b = nullptr;
+        if (qb && kb && vb) {
+            CK(e->alloc(&L.qkv_b, (size_t)(Nq + 2 * Nkv)));
+            CK(hipMemcpyAsync(L.qkv_b, qb, (size_t)Nq * 2, hipMemcpyDeviceToDevice, s));
+            CK(hipMemcpyAsync(L.qkv_b + Nq, kb, (size_t)Nkv * 2, hipMemcpyDeviceToDevice, s));
+            CK(hipMemcpyAsync(L.qkv_b + Nq + Nkv, vb, (size_t)Nkv * 2, hipMemcpyDeviceToDevice, s));
+        }
+        CK(e->alloc(&L.w13, (size_t)2 * I * H));
+        CK(launch_pack_w13(s, gw, uw, L.w13, I, H));
+        CK(hipStreamSynchronize(s));
+        for (const char* n : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                              "mlp.gate_proj.weight", "mlp.up_proj.weight"})
+            drop(e, p + n);
+    }
+    // ---- rope frequency tables (same fp32 formula as the oracle / transformers)
+    {
+        std::vector<float> vf(32), lf(64);
+        for (int i = 0; i < 32; ++i) vf[i] = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+        for (int i = 0; i < 64; ++i) lf[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / 128.0f);
+        CK(e->alloc(&e->v_inv_freq, 32));
+        CK(e->alloc(&e->lm_inv_freq, 64));
+        CK(hipMemcpyAsync(e->v_inv_freq, vf.data(), 32 * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(e->lm_inv_freq, lf.data(), 64 * 4, hipMemcpyHostToDevice, s));
+        CK(hipStreamSynchronize(s));
+    }
+    e->finalized = true;
+    return DOTS_OK;
+}
+
+int alloc_workspaces(DotsEngine* e) {
+    const DotsConfig& c = e->cfg;
+    const int E = c.v_embed_dim, H = c.hidden_size, Nq = c.num_heads * 128, Nkv = c.num_kv_heads * 128;
+    const int Mg = E * c.v_merge * c.v_merge;
+    e->P = c.max_patches;
+    e->Ppad = e->P + 64 * 256;                    // every image padded to a multiple of 64 keys
+    const int kpad = (int)round_up(c.v_channels * c.v_patch * c.v_patch, 64);
+    CK(e->alloc(&e->v_xa, (size_t)e->P * kpad));
+    CK(e->alloc(&e->v_x, (size_t)e->P * E));
+    CK(e->alloc(&e->v_xn, (size_t)e->P * E));
+    CK(e->alloc(&e->v_qkv, (size_t)e->P * 3 * E));
+    CK(e->alloc(&e->v_q, (size_t)e->P * E));
+    CK(e->alloc(&e->v_k, (size_t)(e->P + 64) * E));
+    CK(e->alloc(&e->v_vt, (size_t)e->Ppad * E));
+    CK(e->alloc(&e->v_att, (size_t)e->P * E));
+    CK(e->alloc(&e->v_act, (size_t)e->P * c.v_intermediate));
+    CK(e->alloc(&e->v_mh, (size_t)(e->P / 4 + 1) * Mg));
+    CK(e->alloc(&e->vis, (size_t)(e->P / 4 + 1) * H));
+    CK(e->alloc(&e->v_cs, (size_t)e->P * 64));
+    CK(e->alloc(&e->v_pos, (size_t)e->P * 2));
+    CK(e->alloc(&e->v_tiles, (size_t)(e->P / 64 + 256)));
+    CK(e->alloc(&e->v_qblocks, (size_t)(e->P / 128 + 256)));
+
+    e->TP = c.max_prefill_tokens;
+    e->TPpad = e->TP + 64 * c.max_batch;
+    CK(e->alloc(&e->p_x, (size_t)e->TP * H));
+    CK(e->alloc(&e->p_xn, (size_t)e->TP * H));
+    CK(e->alloc(&e->p_qkv, (size_t)e->TP * (Nq + 2 * Nkv)));
+    CK(e->alloc(&e->p_q, (size_t)e->TP * Nq));
+    CK(e->alloc(&e->p_k, (size_t)(e->TP + 64) * Nkv));
+    CK(e->alloc(&e->p_vt, (size_t)e->TPpad * Nkv));
+    CK(e->alloc(&e->p_att, (size_t)e->TP * Nq));
+    CK(e->alloc(&e->p_act, (size_t)e->TP * c.intermediate_size));
+    CK(e->alloc(&e->p_cs, (size_t)e->TP * 64));
+    CK(e->alloc(&e->p_pos, (size_t)e->TP));
+    CK(e->alloc(&e->p_src, (size_t)e->TP));
+    CK(e->alloc(&e->p_last, (size_t)16));
+    CK(e->alloc(&e->p_tiles, (size_t)(e->TP / 64 + c.max_batch + 1)));
+    CK(e->alloc(&e->p_qblocks, (size_t)(e->TP / 128 + c.max_batch + 1)));
+
+    e->max_pages = (c.max_seq_len + 63) / 64;
+    e->pool_layer_elems = (size_t)c.max_batch * e->max_pages * c.num_kv_heads * 2 * 8192;
+    CK(e->alloc(&e->pool, e->pool_layer_elems * c.num_layers));
+    const int mb = std::max(c.max_batch, 16);
+    CK(e->alloc(&e->block_table, (size_t)mb * e->max_pages));
+    CK(e->alloc(&e->ctx_len, (size_t)mb));
+    CK(e->alloc(&e->cur_tokens, (size_t)mb));
+    CK(e->alloc(&e->out_ids, (size_t)mb * c.max_seq_len));
+    CK(e->alloc(&e->out_lens, (size_t)mb));
+    CK(e->alloc(&e->finished, (size_t)mb));
+    CK(e->alloc(&e->eos_ids, (size_t)16));
+    CK(e->alloc(&e->forced, (size_t)mb));
+    CK(hipMemsetAsync(e->forced, 0xff, (size_t)mb * 4, e->stream));
+    CK(e->alloc(&e->d_h, (size_t)16 * H));
+    CK(e->alloc(&e->d_xn, (size_t)16 * H));
+    CK(e->alloc(&e->d_q, (size_t)16 * Nq));
+    CK(e->alloc(&e->d_att, (size_t)16 * Nq));
+    CK(e->alloc(&e->d_act, (size_t)16 * c.intermediate_size));
+    size_t pmax = 0;
+    auto upd = [&](int N, int K) { pmax = std::max(pmax, (size_t)skinny_splits(N, K) * 16 * N); };
+    upd(Nq + 2 * Nkv, H); upd(H, Nq); upd(2 * c.intermediate_size, H); upd(H, c.intermediate_size); upd(c.vocab_size, H);
+    CK(e->alloc(&e->d_partial, pmax));
+    CK(e->alloc(&e->d_part_o, (size_t)16 * c.num_heads * 64 * 128));
+    CK(e->alloc(&e->d_part_ml, (size_t)16 * c.num_heads * 64 * 2));
+    e->d_logits = e->d_partial;                  // lm_head runs with one split: its slab [16][V] IS the logits
+    // identity paging: sequence slot b owns pages [b*max_pages, (b+1)*max_pages)
+    e->hp_table.resize((size_t)mb * e->max_pages);
+    for (int b = 0; b < mb; ++b)
+        for (int p = 0; p < e->max_pages; ++p) e->hp_table[(size_t)b * e->max_pages + p] = (b % c.max_batch) * e->max_pages + p;
+    CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, e->stream));
+    for (auto& ev : e->ev) CK(hipEventCreate(&ev));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+// sequences -> 64-token tiles and 128-row query blocks
+void build_worklists(const std::vector<int>& lens, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used) {
+    tiles.clear();
+    qblocks.clear();
+    int tok0 = 0, pad0 = 0;
+    for (size_t s = 0; s < lens.size(); ++s) {
+        const int n = lens[s];
+        for (int t = 0; t * 64 < n; ++t) tiles.push_back(Tile64{tok0 + t * 64, std::min(64, n - t * 64), pad0 + t * 64, (int)s, t, 0});
+        for (int q = 0; q < n; q += 128) qblocks.push_back(QBlock{q, n, tok0, pad0});
+        tok0 += n;
+        pad0 += (int)round_up(n, 64);
+    }
+    *Tpad_used = pad0;
+}
+
+hipError_t attn_event(DotsEngine* e, int idx) {
+    while ((int)e->attn_ev.size() <= idx) {
+        hipEvent_t ev;
+        hipError_t r = hipEventCreate(&ev);
+        if (r != hipSuccess) return r;
+        e->attn_ev.push_back(ev);
+    }
+    return hipEventRecord(e->attn_ev[idx], e->stream);
+}
+
+int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* grid, int n_img, void* out_dev) {
+    const DotsConfig& c = e->cfg;
+    hipStream_t s = e->stream;
+    const int E = c.v_embed_dim, Hh = c.v_heads, m = c.v_merge;
+    if (N > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches %lld > max_patches %lld", (long long)N, (long long)e->P);
+    if (c.v_temporal_patch != 1) return e->fail(DOTS_E_INVALID, "temporal_patch_size != 1 is not supported");
+    // ---- host: position ids (block-major over merge x merge groups), sequences
+    e->h_pos.resize((size_t)N * 2);
+    std::vector<int> lens;
+    int64_t off = 0;
+    double attn_flops = 0;
+    for (int i = 0; i < n_img; ++i) {
+        const int64_t t = grid[i * 3], h = grid[i * 3 + 1], w = grid[i * 3 + 2];
+        if (h % m || w % m || t < 1) return e->fail(DOTS_E_INVALID, "grid_thw[%d] not divisible by merge size", i);
+        if (off + t * h * w > N) return e->fail(DOTS_E_INVALID, "grid_thw does not match total_patches");
+        for (int64_t tt = 0; tt < t; ++tt) {
+            for (int64_t gh = 0; gh < h / m; ++gh)
+                for (int64_t gw = 0; gw < w / m; ++gw)
+                    for (int mh = 0; mh < m; ++mh)
+                        for (int mw = 0; mw < m; ++mw) {
+                            e->h_pos[off * 2] = (int32_t)(gh * m + mh);
+                            e->h_pos[off * 2 + 1] = (int32_t)(gw * m + mw);
+                            ++off;
+                        }
+            lens.push_back((int)(h * w));
+            attn_flops += 4.0 * (double)(h * w) * (double)(h * w) * E;
+        }
+    }
+    if (off != N) return e->fail(DOTS_E_INVALID, "grid_thw covers %lld patches, total_patches is %lld", (long long)off, (long long)N);
+    if (lens.size() > 256) return e->fail(DOTS_E_CAPACITY, "more than 256 images per call");
+    int64_t Tpad = 0;
+    build_worklists(lens, e->h_tiles, e->h_qblocks, &Tpad);
+    CK(hipMemcpyAsync(e->v_pos, e->h_pos.data(), e->h_pos.size() * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->v_tiles, e->h_tiles.data(), e->h_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->v_qblocks, e->h_qblocks.data(), e->h_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
+
+    CK(hipEventRecord(e->ev[0], s));
+    CK(launch_patch_prep(s, pix_dev, e->v_xa, N, e->patch_k, e->patch_kpad));
+    CK(launch_gemm(s, e->v_xa, e->patch_w, e->patch_b, nullptr, e->v_xn, N, E, e->patch_kpad, e->patch_kpad, E, EPI_NONE));
+    CK(launch_rmsnorm(s, e->v_xn, e->patch_norm, e->v_x, N, E, c.v_rms_eps));
+    CK(launch_rope_table(s, e->v_pos, e->v_inv_freq, e->v_cs, N, 1));
+    const float scale = 1.0f / sqrtf(128.0f);
+    e->attn_pairs = 0;
+    for (int i = 0; i < c.v_layers; ++i) {
+        const VLayer& L = e->vl[i];
+        CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
+        CK(launch_gemm(s, e->v_xn, L.qkv_w, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, E, 3 * E, EPI_NONE));
+        CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
+        CK(attn_event(e, 2 * i));
+        CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale));
+        CK(attn_event(e, 2 * i + 1));
+        e->attn_pairs = i + 1;
+        CK(launch_gemm(s, e->v_att, L.proj_w, L.proj_b, e->v_x, e->v_x, N, E, E, E, E, EPI_RESIDUAL));
+        CK(launch_rmsnorm(s, e->v_x, L.norm2, e->v_xn, N, E, c.v_rms_eps));
+        CK(launch_gemm(s, e->v_xn, L.w13, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, E, c.v_intermediate, EPI_SWIGLU));
+        CK(launch_gemm(s, e->v_act, L.w2, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, c.v_intermediate, E, EPI_RESIDUAL));
+    }
+    const bf16_t* xin = e->v_x;
+    if (c.v_post_norm) {
+        CK(launch_rmsnorm(s, e->v_x, e->v_post_norm, e->v_xn, N, E, c.v_rms_eps));
+        xin = e->v_xn;
+    }
+    CK(launch_layernorm(s, xin, e->m_ln_w, e->m_ln_b, e->v_att, N, E, c.v_ln_eps));
+    const int g = m * m, Mg = E * g;
+    const int64_t R = N / g;
+    CK(launch_gemm(s, e->v_att, e->m0_w, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, Mg, EPI_GELU));
+    CK(launch_gemm(s, e->v_mh, e->m2_w, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, Mg, c.hidden_size, EPI_NONE));
+    CK(hipEventRecord(e->ev[1], s));
+    e->vis_rows = R;
+    if (out_dev) CK(hipMemcpyAsync(out_dev, e->vis, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
+
+    // algorithmic flops
+    e->stats.vit_patches = N;
+    e->stats.vit_attn_flops = attn_flops * c.v_layers;
+    e->stats.vit_flops = e->stats.vit_attn_flops +
+                         (double)c.v_layers * 2.0 * N * (4.0 * E * E + 3.0 * E * c.v_intermediate) +
+                         2.0 * N * e->patch_k * E + 2.0 * (double)R * ((double)Mg * Mg + (double)Mg * c.hidden_size);
+    return DOTS_OK;
+}
+
+int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
+    const DotsConfig& c = e->cfg;
+    hipStream_t s = e->stream;
+    const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, Nkv = Hkv * 128, NQKV = Nq + 2 * Nkv;
+    if (B < 1 || B > c.max_batch || B > 16) return e->fail(DOTS_E_CAPACITY, "batch %d exceeds max_batch %d (<= 16)", B, c.max_batch);
+    int64_t T = 0;
+    std::vector<int> L(B);
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] < 1 || lens[b] >= c.max_seq_len) return e->fail(DOTS_E_CAPACITY, "prompt %d length %d not in [1, max_seq_len)", b, lens[b]);
+        L[b] = lens[b];
+        T += lens[b];
+    }
+    if (T > e->TP) return e->fail(DOTS_E_CAPACITY, "packed prompt tokens %lld > max_prefill_tokens %lld", (long long)T, (long long)e->TP);
+    e->hp_pos.resize(T); e->hp_src.resize(T); e->hp_last.assign(16, 0);
+    int64_t t = 0, vis_used = 0;
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < L[b]; ++i, ++t) {
+            e->hp_pos[t] = i;
+            const int id = ids[t];
+            if (id == c.image_token_id) e->hp_src[t] = -(int32_t)(++vis_used);
+            else if (id < 0 || id >= c.vocab_size) return e->fail(DOTS_E_INVALID, "token id %d out of range", id);
+            else e->hp_src[t] = id;
+        }
+        e->hp_last[b] = (int32_t)(t - 1);
+    }
+    if (vis_used != (vis_used ? e->vis_rows : 0))
+        return e->fail(DOTS_E_STATE, "prompt has %lld image tokens but the vision tower produced %lld rows", (long long)vis_used, (long long)e->vis_rows);
+    int64_t Tpad = 0;
+    build_worklists(L, e->hp_tiles, e->hp_qblocks, &Tpad);
+    CK(hipMemcpyAsync(e->p_pos, e->hp_pos.data(), T * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->p_src, e->hp_src.data(), T * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), 16 * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->p_tiles, e->hp_tiles.data(), e->hp_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->p_qblocks, e->hp_qblocks.data(), e->hp_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->ctx_len, lens, B * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemsetAsync(e->out_lens, 0, 16 * 4, s));
+    CK(hipMemsetAsync(e->finished, 0, 16 * 4, s));
+
+    CK(hipEventRecord(e->ev[2], s));
+    CK(launch_embed_gather(s, e->p_src, e->embed, e->vis, e->p_x, T, H));
+    CK(launch_rope_table(s, e->p_pos, e->lm_inv_freq, e->p_cs, T, 0));
+    const float scale = 1.0f / sqrtf(128.0f);
+    const int n_tiles = (int)e->hp_tiles.size();
+    for (int i = 0; i < c.num_layers; ++i) {
+        const LLayer& Lw = e->ll[i];
+        bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
+        CK(launch_rmsnorm(s, e->p_x, Lw.ln1, e->p_xn, T, H, c.rms_norm_eps));
+        CK(launch_gemm(s, e->p_xn, Lw.qkv_w, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, H, NQKV, EPI_NONE));
+        CK(launch_qkv_rope_split(s, e->p_qkv, e->p_cs, e->p_tiles, n_tiles, e->p_q, e->p_k, e->p_vt, T, Tpad, Hq, Hkv));
+        CK(launch_kv_to_pages(s, e->p_k, e->p_qkv, e->p_tiles, n_tiles, e->block_table, e->max_pages, pool_l, T, Hq, Hkv));
+        CK(launch_flash_attn(s, e->p_q, e->p_k, e->p_vt, e->p_att, e->p_qblocks, (int)e->hp_qblocks.size(), T, Tpad, Hq, Hkv, 1, scale));
+        CK(launch_gemm(s, e->p_att, Lw.o_w, nullptr, e->p_x, e->p_x, T, H, Nq, Nq, H, EPI_RESIDUAL));
+        CK(launch_rmsnorm(s, e->p_x, Lw.ln2, e->p_xn, T, H, c.rms_norm_eps));
+        CK(launch_gemm(s, e->p_xn, Lw.w13, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, H, c.intermediate_size, EPI_SWIGLU));
+        CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL));
+    }
+    // last position of every sequence -> final norm -> lm_head -> first token
+    CK(launch_gather_rows(s, e->p_x, e->p_last, e->d_h, B, H));
+    CK(launch_rmsnorm(s, e->d_h, e->final_norm, e->d_xn, B, H, c.rms_norm_eps));
+    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head, e->d_logits, c.vocab_size, H, 1));
+    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->cur_tokens, e->ctx_len, e->out_ids, e->out_lens,
+                          e->finished, e->eos_ids, e->n_eos, e->out_cap, 0, e->forced));
+    CK(hipEventRecord(e->ev[3], s));
+    e->B = B;
+    e->h_prompt_lens = L;
+    e->steps_done = 0;
+    e->vis_rows = 0;
+    e->stats.prefill_tokens = T;
+    double pf = 0;
+    const double lin = (double)c.num_layers * ((double)H * NQKV + (double)Nq * H + 3.0 * H * c.intermediate_size);
+    for (int b = 0; b < B; ++b) pf += 2.0 * lin * L[b] + (double)c.num_layers * 2.0 * L[b] * (double)L[b] * Nq + 2.0 * (double)c.vocab_size * H;
+    e->stats.prefill_flops = pf;
+    return DOTS_OK;
+}
+
+// every launch of one decode step; identical in eager mode and under graph capture
+int decode_step_launches(DotsEngine* e, int n_splits) {
+    const DotsConfig& c = e->cfg;
+    hipStream_t s = e->stream;
+    const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, NQKV = Nq + 2 * Hkv * 128, I = c.intermediate_size;
+    const int B = e->B;
+    const float scale = 1.0f / sqrtf(128.0f);
+    CK(launch_embed_rmsnorm(s, e->cur_tokens, e->embed, e->ll[0].ln1, e->d_h, e->d_xn, B, H, c.rms_norm_eps));
+    for (int i = 0; i < c.num_layers; ++i) {
+        const LLayer& L = e->ll[i];
+        bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
+        int S = skinny_splits(NQKV, H);
+        CK(launch_gemm_skinny(s, e->d_xn, L.qkv_w, e->d_partial, NQKV, H, S));
+        CK(launch_qkv_post_decode(s, e->d_partial, S, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, Hq, Hkv));
+        CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
+        CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->d_att, B, Hq, Hkv, n_splits));
+        S = skinny_splits(H, Nq);
+        CK(launch_gemm_skinny(s, e->d_att, L.o_w, e->d_partial, H, Nq, S));
+        CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, L.ln2, e->d_xn, B, H, c.rms_norm_eps));
+        S = skinny_splits(2 * I, H);
+        CK(launch_gemm_skinny(s, e->d_xn, L.w13, e->d_partial, 2 * I, H, S));
+        CK(launch_reduce_swiglu(s, e->d_partial, S, e->d_act, I, B));
+        S = skinny_splits(H, I);
+        CK(launch_gemm_skinny(s, e->d_act, L.down_w, e->d_partial, H, I, S));
+        const bf16_t* next_norm = (i + 1 < c.num_layers) ? e->ll[i + 1].ln1 : e->final_norm;
+        CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, next_norm, e->d_xn, B, H, c.rms_norm_eps));
+    }
+    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head, e->d_logits, c.vocab_size, H, 1));
+    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->cur_tokens, e->ctx_len, e->out_ids, e->out_lens,
+                          e->finished, e->eos_ids, e->n_eos, e->out_cap, 1, e->forced));
+    return DOTS_OK;
+}
+
+int splits_for_ctx(int max_ctx) {
+    const int pages = (max_ctx + 63) / 64;
+    return std::max(1, std::min((pages + 3) / 4, 64));
+}
+
+double decode_step_bytes(const DotsConfig& c) {
+    const double H = c.hidden_size, Nq = c.num_heads * 128.0, Nkv = c.num_kv_heads * 128.0, I = c.intermediate_size;
+    const double per_layer = H * (Nq + 2 * Nkv) + (c.attention_bias ? Nq + 2 * Nkv : 0) + Nq * H + 3 * H * I + 2 * H;
+    return 2.0 * (c.num_layers * per_layer + H + (double)c.vocab_size * H);
+}
+
+}  // namespace
+
+// ===================================================================================== C ABI
+extern "C" {
+
+const char* dots_last_error(DotsEngine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+void* dots_stream(DotsEngine* e) { return e ? (void*)e->stream : nullptr; }
+
+int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return DOTS_E_INVALID; }
+    const DotsConfig& c = *cfg;
+    auto bad = [&](const char* m) { g_create_error = m; return DOTS_E_INVALID; };
+    if (c.head_dim != 128) return bad("head_dim must be 128");
+    if (c.v_embed_dim != c.v_heads * 128) return bad("vision head_dim must be 128");
+    if (c.num_heads % c.num_kv_heads || c.num_heads / c.num_kv_heads > 16) return bad("unsupported GQA group");
+    if (c.hidden_size % 128 || c.v_embed_dim % 128 || c.vocab_size % 128) return bad("hidden sizes and vocab must be multiples of 128");
+    if (c.intermediate_size % 64 || c.v_intermediate % 64) return bad("intermediate sizes must be multiples of 64");
+    if (c.hidden_size > 2048) return bad("hidden_size > 2048 not supported by the decode kernels");
+    if (c.max_batch < 1 || c.max_batch > 16) return bad("max_batch must be in [1,16]");
+    if (c.max_seq_len < 64 || c.max_patches < 4 || c.max_prefill_tokens < 1) return bad("capacity fields too small");
+    if (c.v_merge < 1 || c.v_temporal_patch != 1) return bad("unsupported vision patching");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return DOTS_E_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return DOTS_E_HIP; }
+    DotsEngine* e = new DotsEngine();
+    e->cfg = c;
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return DOTS_E_HIP; }
+    int r = alloc_workspaces(e);
+    if (r != DOTS_OK) { g_create_error = e->err; dots_destroy(e); return r; }
+    *out = e;
+    return DOTS_OK;
+}
+
+void dots_destroy(DotsEngine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
+    for (auto& ev : e->attn_ev) hipEventDestroy(ev);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int dots_load_weight(DotsEngine* e, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !data || !shape || ndim < 1) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
+    if (e->finalized) return e->fail(DOTS_E_STATE, "weights already finalized");
+    CK(hipSetDevice(e->device));
+    Tensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    const size_t esz = dtype == DOTS_DTYPE_F32 ? 4 : 2;
+    if (dtype != DOTS_DTYPE_BF16 && dtype != DOTS_DTYPE_F32 && dtype != DOTS_DTYPE_F16) return e->fail(DOTS_E_INVALID, "unsupported dtype %d", dtype);
+    CK(e->alloc(&t.p, (size_t)n));
+    if (dtype == DOTS_DTYPE_BF16) {
+        CK(hipMemcpyAsync(t.p, data, n * 2, hipMemcpyHostToDevice, e->stream));
+        CK(hipStreamSynchronize(e->stream));
+    } else {
+        void* tmp = nullptr;
+        CK(hipMalloc(&tmp, n * esz));
+        CK(hipMemcpyAsync(tmp, data, n * esz, hipMemcpyHostToDevice, e->stream));
+        CK(launch_convert_to_bf16(e->stream, tmp, dtype, t.p, n));
+        CK(hipStreamSynchronize(e->stream));
+        hipFree(tmp);
+    }
+    drop(e, name);
+    e->raw[name] = t;
+    return DOTS_OK;
+}
+
+int dots_finalize_weights(DotsEngine* e) {
+    if (!e) return DOTS_E_INVALID;
+    if (e->finalized) return DOTS_OK;
+    CK(hipSetDevice(e->device));
+    return finalize_weights(e);
+}
+
+int dots_vit_forward(DotsEngine* e, const float* pixel_values, int on_device, int64_t total_patches,
+                     const int64_t* grid_thw, int n_img, void* out_embeds_dev) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    if (!pixel_values || !grid_thw || n_img < 1 || total_patches < 1) return e->fail(DOTS_E_INVALID, "bad vit_forward arguments");
+    CK(hipSetDevice(e->device));
+    const float* pix = pixel_values;
+    if (!on_device) {
+        if (total_patches > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches exceeds max_patches");
+        if (!e->v_pix) CK(e->alloc(&e->v_pix, (size_t)e->P * e->patch_k));
+        CK(hipMemcpyAsync(e->v_pix, pixel_values, (size_t)total_patches * e->patch_k * 4, hipMemcpyHostToDevice, e->stream));
+        pix = e->v_pix;
+    }
+    return vit_forward(e, pix, total_patches, grid_thw, n_img, out_embeds_dev);
+}
+
+int dots_prefill(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt_lens, int B) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    if (!input_ids || !prompt_lens) return e->fail(DOTS_E_INVALID, "null argument");
+    CK(hipSetDevice(e->device));
+    if (e->out_cap <= 0) e->out_cap = e->cfg.max_seq_len;
+    return prefill(e, input_ids, prompt_lens, B);
+}
+
+int dots_decode_step(DotsEngine* e) {
+    if (!e) return DOTS_E_INVALID;
+    if (e->B < 1) return e->fail(DOTS_E_STATE, "no prefilled batch");
+    CK(hipSetDevice(e->device));
+    int max_ctx = 0;
+    for (int b = 0; b < e->B; ++b) max_ctx = std::max(max_ctx, e->h_prompt_lens[b] + e->steps_done + 1);
+    if (max_ctx >= e->cfg.max_seq_len) return e->fail(DOTS_E_CAPACITY, "sequence reached max_seq_len");
+    RET(decode_step_launches(e, splits_for_ctx(max_ctx)));
+    e->steps_done += 1;
+    return DOTS_OK;
+}
+
+int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt_lens, int B,
+                  const float* pixel_values, int on_device, int64_t total_patches, const int64_t* grid_thw, int n_img,
+                  int max_new_tokens, const int32_t* eos_ids, int n_eos, int32_t* out_ids, int32_t* out_lens) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    if (!input_ids || !prompt_lens || !out_ids || !out_lens || max_new_tokens < 1) return e->fail(DOTS_E_INVALID, "bad generate arguments");
+    if (n_eos < 0 || n_eos > 16) return e->fail(DOTS_E_INVALID, "n_eos must be in [0,16]");
+    CK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    int max_prompt = 0;
+    for (int b = 0; b < B; ++b) max_prompt = std::max(max_prompt, prompt_lens[b]);
+    if (max_prompt + max_new_tokens > e->cfg.max_seq_len)
+        return e->fail(DOTS_E_CAPACITY, "prompt (%d) + max_new_tokens (%d) exceeds max_seq_len %d", max_prompt, max_new_tokens, e->cfg.max_seq_len);
+    e->stats = DotsStats{};
+    CK(hipEventRecord(e->ev[6], s));
+    e->vis_rows = 0;
+    if (n_img > 0) RET(dots_vit_forward(e, pixel_values, on_device, total_patches, grid_thw, n_img, nullptr));
+    e->n_eos = n_eos;
+    if (n_eos) CK(hipMemcpyAsync(e->eos_ids, eos_ids, n_eos * 4, hipMemcpyHostToDevice, s));
+    e->out_cap = max_new_tokens;
+    RET(prefill(e, input_ids, prompt_lens, B));
+
+    // ---- decode loop: one captured graph replayed max_new_tokens-1 times
+    CK(hipEventRecord(e->ev[4], s));
+    const int n_splits = splits_for_ctx(max_prompt + max_new_tokens);
+    const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph && max_new_tokens > 1) {
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int r = decode_step_launches(e, n_splits);
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (r != DOTS_OK) return r;
+        CK(ce);
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
+    std::vector<int32_t> fin(16);
+    int steps = 0;
+    for (int step = 1; step < max_new_tokens; ++step) {
+        if (exec) CK(hipGraphLaunch(exec, s));
+        else RET(decode_step_launches(e, n_splits));
+        ++steps;
+        if (n_eos && (step % 16 == 0)) {       // early exit once every sequence hit EOS
+            CK(hipMemcpyAsync(fin.data(), e->finished, B * 4, hipMemcpyDeviceToHost, s));
+            CK(hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all = all && fin[b];
+            if (all) break;
+        }
+    }
+    CK(hipEventRecord(e->ev[5], s));
+    CK(hipEventRecord(e->ev[7], s));
+    e->steps_done = steps;
+    std::vector<int32_t> tmp((size_t)B * max_new_tokens);
+    CK(hipMemcpyAsync(tmp.data(), e->out_ids, tmp.size() * 4, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(out_lens, e->out_lens, B * 4, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    std::memcpy(out_ids, tmp.data(), tmp.size() * 4);
+    if (exec) hipGraphExecDestroy(exec);
+    if (graph) hipGraphDestroy(graph);
+
+    // ---- stats
+    e->stats.decode_steps = steps;
+    int64_t newtok = 0;
+    double kvb = 0;
+    const double kv_tok = (double)e->cfg.num_layers * e->cfg.num_kv_heads * 128 * 2 * 2;
+    for (int b = 0; b < B; ++b) {
+        newtok += out_lens[b];
+        for (int st = 0; st < steps; ++st) kvb += (double)(prompt_lens[b] + st + 1) * kv_tok;
+    }
+    e->stats.new_tokens = newtok;
+    e->stats.decode_bytes = (double)steps * decode_step_bytes(e->cfg) + kvb;
+    return DOTS_OK;
+}
+
+int dots_get_stats(DotsEngine* e, DotsStats* out) {
+    if (!e || !out) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(e->stream));
+    auto el = [&](int a, int b) { float ms = 0; if (hipEventElapsedTime(&ms, e->ev[a], e->ev[b]) != hipSuccess) ms = 0; return ms; };
+    e->stats.vit_ms = e->stats.vit_patches ? el(0, 1) : 0;
+    e->stats.prefill_ms = e->stats.prefill_tokens ? el(2, 3) : 0;
+    e->stats.decode_ms = e->stats.decode_steps ? el(4, 5) : 0;
+    e->stats.total_ms = e->stats.decode_steps || e->stats.new_tokens ? el(6, 7) : 0;
+    float a = 0;
+    for (int i = 0; i < e->attn_pairs; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->attn_ev[2 * i], e->attn_ev[2 * i + 1]) == hipSuccess) a += ms;
+    }
+    e->stats.vit_attn_ms = a;
+    e->stats.vit_attn_launches = e->attn_pairs;
+    *out = e->stats;
+    return DOTS_OK;
+}
+
+int dots_get_logits(DotsEngine* e, float* out) {
+    if (!e || !out) return DOTS_E_INVALID;
+    if (e->B < 1) return e->fail(DOTS_E_STATE, "no prefilled batch");
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpyAsync(out, e->d_logits, (size_t)e->B * e->cfg.vocab_size * 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_set_next_tokens(DotsEngine* e, const int32_t* tokens, int B) {
+    if (!e || !tokens || B != e->B) return e ? e->fail(DOTS_E_INVALID, "bad set_next_tokens arguments") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpyAsync(e->cur_tokens, tokens, B * 4, hipMemcpyHostToDevice, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_get_last_tokens(DotsEngine* e, int32_t* out) {
+    if (!e || !out) return DOTS_E_INVALID;
+    if (e->B < 1) return e->fail(DOTS_E_STATE, "no prefilled batch");
+    CK(hipSetDevice(e->device));
+    std::vector<int32_t> lens(16), ids((size_t)16 * std::max(1, e->out_cap));
+    CK(hipMemcpyAsync(lens.data(), e->out_lens, e->B * 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipMemcpyAsync(ids.data(), e->out_ids, (size_t)e->B * e->out_cap * 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < e->B; ++b) out[b] = lens[b] > 0 ? ids[(size_t)b * e->out_cap + lens[b] - 1] : -1;
+    return DOTS_OK;
+}
+
+int dots_synchronize(DotsEngine* e) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_dev_alloc(DotsEngine* e, int64_t bytes, void** out) {
+    if (!e || !out || bytes < 0) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    uint8_t* p = nullptr;
+    CK(e->alloc(&p, (size_t)bytes));
+    *out = p;
+    return DOTS_OK;
+}
+int dots_dev_free(DotsEngine* e, void* p) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(e->stream));
+    e->release(p);
+    return DOTS_OK;
+}
+int dots_memcpy_h2d(DotsEngine* e, void* dst, const void* src, int64_t bytes) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+int dots_memcpy_d2h(DotsEngine* e, void* dst, const void* src, int64_t bytes) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+// ---------------------------------------------------------------- single-kernel entry points
+int dots_op_rmsnorm(DotsEngine* e, const void* x, const void* w, void* y, int64_t rows, int dim, float eps) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(launch_rmsnorm(e->stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rows, dim, eps));
+    return DOTS_OK;
+}
+int dots_op_layernorm(DotsEngine* e, const void* x, const void* w, const void* b, void* y, int64_t rows, int dim, float eps) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(launch_layernorm(e->stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, dim, eps));
+    return DOTS_OK;
+}
+int dots_op_gemm(DotsEngine* e, const void* A, const void* W, const void* bias, const void* residual, void* C,
+                 int64_t M, int N, int K, int epilogue) {
+    if (!e) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    const int ldc = epilogue == EPI_SWIGLU ? N / 2 : N;
+    CK(launch_gemm(e->stream, (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)residual, C, M, N, K, K, ldc, epilogue));
+    return DOTS_OK;
+}
+
+static int upload_lists(DotsEngine* e, const int32_t* cu, int n_seq, std::vector<Tile64>& tiles, std::vector<QBlock>& qb,
+                        Tile64** d_tiles, QBlock** d_qb, int64_t* Tpad) {
+    std::vector<int> lens(n_seq);
+    for (int i = 0; i < n_seq; ++i) lens[i] = cu[i + 1] - cu[i];
+    build_worklists(lens, tiles, qb, Tpad);
+    CK(e->alloc(d_tiles, tiles.size() + 1));
+    CK(e->alloc(d_qb, qb.size() + 1));
+    CK(hipMemcpyAsync(*d_tiles, tiles.data(), tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, e->stream));
+    CK(hipMemcpyAsync(*d_qb, qb.data(), qb.size() * sizeof(QBlock), hipMemcpyHostToDevice, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_op_flash_attn(DotsEngine* e, const void* q, const void* k, const void* vt, void* out, const int32_t* cu, int n_seq,
+                       int Hq, int Hkv, int causal, float scale) {
+    if (!e || !cu || n_seq < 1) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    std::vector<Tile64> tiles;
+    std::vector<QBlock> qb;
+    Tile64* dt = nullptr;
+    QBlock* dq = nullptr;
+    int64_t Tpad = 0;
+    RET(upload_lists(e, cu, n_seq, tiles, qb, &dt, &dq, &Tpad));
+    const int64_t T = cu[n_seq];
+    hipError_t r = launch_flash_attn(e->stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, dq, (int)qb.size(), T, Tpad, Hq, Hkv, causal, scale);
+    hipStreamSynchronize(e->stream);
+    e->release(dt);
+    e->release(dq);
+    CK(r);
+    return DOTS_OK;
+}
+
+int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, void* vt, const int32_t* cu, int n_seq,
+                           const int32_t* pos_host, int Hq, int Hkv, int rope2d, float theta) {
+    if (!e || !cu || n_seq < 1 || !pos_host) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    std::vector<Tile64> tiles;
+    std::vector<QBlock> qb;
+    Tile64* dt = nullptr;
+    QBlock* dq = nullptr;
+    int64_t Tpad = 0;
+    RET(upload_lists(e, cu, n_seq, tiles, qb, &dt, &dq, &Tpad));
+    const int64_t T = cu[n_seq];
+    int32_t* dpos = nullptr;
+    float2* cs = nullptr;
+    float* freq = nullptr;
+    const int nf = rope2d ? 32 : 64;
+    std::vector<float> f(nf);
+    for (int i = 0; i < nf; ++i) f[i] = 1.0f / powf(theta, (float)(2 * i) / (rope2d ? 64.0f : 128.0f));
+    CK(e->alloc(&dpos, (size_t)T * (rope2d ? 2 : 1)));
+    CK(e->alloc(&cs, (size_t)T * 64));
+    CK(e->alloc(&freq, (size_t)nf));
+    CK(hipMemcpyAsync(dpos, pos_host, (size_t)T * (rope2d ? 2 : 1) * 4, hipMemcpyHostToDevice, e->stream));
+    CK(hipMemcpyAsync(freq, f.data(), nf * 4, hipMemcpyHostToDevice, e->stream));
+    CK(launch_rope_table(e->stream, dpos, freq, cs, T, rope2d));
+    hipError_t r = launch_qkv_rope_split(e->stream, (const bf16_t*)qkv, cs, dt, (int)tiles.size(), (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, Tpad, Hq, Hkv);
+    hipStreamSynchronize(e->stream);
+    e->release(dt); e->release(dq); e->release(dpos); e->release(cs); e->release(freq);
+    CK(r);
+    return DOTS_OK;
+}
+
+int dots_op_gemm_skinny(DotsEngine* e, const void* X, const void* W, void* out_f32, int M, int N, int K) {
+    if (!e || M < 1 || M > 16) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    const int S = skinny_splits(N, K);
+    float* partial = nullptr;
+    CK(e->alloc(&partial, (size_t)S * 16 * N));
+    hipError_t r = launch_gemm_skinny(e->stream, (const bf16_t*)X, (const bf16_t*)W, partial, N, K, S);
+    if (r == hipSuccess) r = launch_skinny_reduce_plain(e->stream, partial, (float*)out_f32, N, S);
+    hipStreamSynchronize(e->stream);
+    e->release(partial);
+    CK(r);
+    return DOTS_OK;
+}
+
+}  // extern "C"

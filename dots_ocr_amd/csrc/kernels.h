@@ -1,0 +1,62 @@
+// Host-side launchers of the gfx950 kernels (one per .hip translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4 };
+
+// ---- gemm.hip
+hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R,
+                       void* C, int64_t M, int N, int K, int lda, int ldc, int epi);
+
+// ---- elementwise.hip
+hipError_t launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int dim, float eps);
+hipError_t launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y,
+                            int64_t rows, int dim, float eps);
+// f32 [rows, in_dim] -> bf16 [rows, out_dim] (zero padded columns), the patch-embed GEMM's A operand
+hipError_t launch_patch_prep(hipStream_t s, const float* x, bf16_t* y, int64_t rows, int in_dim, int out_dim);
+// cos/sin tables [T, 64] float2.  2-D: pos [T,2] (h,w), 32 frequencies per axis; 1-D: pos [T], 64 frequencies.
+hipError_t launch_rope_table(hipStream_t s, const int32_t* pos, const float* inv_freq, float2* cs, int64_t T, int two_d);
+// Work item of the 64-token tile kernels: tok0 = first packed token, n = valid tokens (<=64),
+// pad0 = first padded position in the V^T buffer.
+struct Tile64 { int32_t tok0, n, pad0, seq, page, _pad; };   // page = tile index inside its sequence
+hipError_t launch_qkv_rope_split(hipStream_t s, const bf16_t* qkv, const float2* cs, const Tile64* tiles, int n_tiles,
+                                 bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv);
+// x[t] = src[t] >= 0 ? embed[src[t]] : vision[-src[t]-1]
+hipError_t launch_embed_gather(hipStream_t s, const int32_t* src, const bf16_t* embed, const bf16_t* vision, bf16_t* x,
+                               int64_t T, int dim);
+hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, bf16_t* y, int n, int dim);
+
+// ---- attn_prefill.hip
+// One work item = one 128-row query block of one sequence.
+struct QBlock { int32_t q0, n, tok0, pad0; };   // first row in seq, seq length, packed token offset, padded V^T offset
+hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
+                             const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
+                             int causal, float scale);
+
+// ---- decode.hip  (KV page pool layout documented there)
+hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
+                              const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv);
+hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* X, const bf16_t* W, float* partial, int N, int K, int splitk);
+hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk);
+hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
+                                bf16_t* h, bf16_t* xn, int B, int dim, float eps);
+hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
+                                          bf16_t* xn, int B, int dim, float eps);
+hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B);
+hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
+                                  const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
+                                  int max_pages, bf16_t* pool_layer, bf16_t* q_out, int B, int Hq, int Hkv);
+hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
+                              const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
+                              int B, int Hq, int Hkv, int n_splits, float scale);
+hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
+                                      int B, int Hq, int Hkv, int n_splits);
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, int32_t* cur_tokens, int32_t* ctx_len,
+                              int32_t* out_ids, int32_t* out_lens, int32_t* finished, const int32_t* eos_ids, int n_eos,
+                              int max_new_tokens, int advance_ctx, const int32_t* forced);
+// ---- engine.hip helper kernels
+hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
+hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);

@@ -1,0 +1,298 @@
+"""ctypes binding of include/dots_ocr_hip.h — the only way Python reaches the HIP kernels.
+
+No torch types cross this boundary: numpy arrays for host buffers, integers for device pointers
+(torch CUDA tensors are passed by ``data_ptr()``; torch and this library share one HIP runtime).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import DotsConfig
+
+EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_F32 = range(5)
+DTYPE_BF16, DTYPE_F32, DTYPE_F16 = 0, 1, 2
+
+
+class CDotsConfig(C.Structure):
+    _fields_ = [
+        ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("intermediate_size", C.c_int32), ("vocab_size", C.c_int32),
+        ("rope_theta", C.c_float), ("rms_norm_eps", C.c_float),
+        ("attention_bias", C.c_int32), ("image_token_id", C.c_int32),
+        ("v_embed_dim", C.c_int32), ("v_layers", C.c_int32), ("v_heads", C.c_int32), ("v_intermediate", C.c_int32),
+        ("v_patch", C.c_int32), ("v_merge", C.c_int32), ("v_channels", C.c_int32), ("v_temporal_patch", C.c_int32),
+        ("v_rms_eps", C.c_float), ("v_ln_eps", C.c_float),
+        ("v_use_bias", C.c_int32), ("v_post_norm", C.c_int32),
+        ("max_batch", C.c_int32), ("max_seq_len", C.c_int32),
+        ("max_patches", C.c_int64), ("max_prefill_tokens", C.c_int64),
+    ]
+
+
+class CDotsStats(C.Structure):
+    _fields_ = [
+        ("vit_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("total_ms", C.c_float),
+        ("vit_attn_ms", C.c_float), ("vit_attn_launches", C.c_int32),
+        ("vit_gemm_ms", C.c_float), ("decode_steps", C.c_int32),
+        ("vit_patches", C.c_int64), ("prefill_tokens", C.c_int64), ("new_tokens", C.c_int64),
+        ("vit_attn_flops", C.c_double), ("vit_flops", C.c_double), ("prefill_flops", C.c_double),
+        ("decode_bytes", C.c_double),
+    ]
+
+
+class DotsEngineError(RuntimeError):
+    pass
+
+
+_SIGNATURES_SET = False
+
+
+def _prototypes(lib):
+    global _SIGNATURES_SET
+    if _SIGNATURES_SET:
+        return
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    P = C.POINTER
+    sig = {
+        "dots_create": (i32, [P(CDotsConfig), i32, P(vp)]),
+        "dots_destroy": (None, [vp]),
+        "dots_last_error": (C.c_char_p, [vp]),
+        "dots_stream": (vp, [vp]),
+        "dots_load_weight": (i32, [vp, C.c_char_p, vp, i32, P(i64), i32]),
+        "dots_finalize_weights": (i32, [vp]),
+        "dots_vit_forward": (i32, [vp, vp, i32, i64, P(i64), i32, vp]),
+        "dots_prefill": (i32, [vp, P(i32), P(i32), i32]),
+        "dots_decode_step": (i32, [vp]),
+        "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
+        "dots_get_logits": (i32, [vp, P(f32)]),
+        "dots_set_next_tokens": (i32, [vp, P(i32), i32]),
+        "dots_get_last_tokens": (i32, [vp, P(i32)]),
+        "dots_get_stats": (i32, [vp, P(CDotsStats)]),
+        "dots_synchronize": (i32, [vp]),
+        "dots_dev_alloc": (i32, [vp, i64, P(vp)]),
+        "dots_dev_free": (i32, [vp, vp]),
+        "dots_memcpy_h2d": (i32, [vp, vp, vp, i64]),
+        "dots_memcpy_d2h": (i32, [vp, vp, vp, i64]),
+        "dots_op_rmsnorm": (i32, [vp, vp, vp, vp, i64, i32, f32]),
+        "dots_op_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),
+        "dots_op_gemm": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]),
+        "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
+        "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
+        "dots_op_gemm_skinny": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "dots_probe_mfma": (i32, [i32, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _SIGNATURES_SET = True
+
+
+EXPORTED_SYMBOLS = [
+    "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
+    "dots_vit_forward", "dots_prefill", "dots_decode_step", "dots_generate", "dots_get_logits",
+    "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
+    "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
+    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma",
+]
+
+
+def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int, max_prefill_tokens: int) -> CDotsConfig:
+    v = cfg.vision
+    return CDotsConfig(
+        hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers, num_heads=cfg.num_attention_heads,
+        num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+        vocab_size=cfg.vocab_size, rope_theta=cfg.rope_theta, rms_norm_eps=cfg.rms_norm_eps,
+        attention_bias=int(cfg.attention_bias), image_token_id=cfg.image_token_id,
+        v_embed_dim=v.embed_dim, v_layers=v.num_hidden_layers, v_heads=v.num_attention_heads,
+        v_intermediate=v.intermediate_size, v_patch=v.patch_size, v_merge=v.spatial_merge_size,
+        v_channels=v.num_channels, v_temporal_patch=v.temporal_patch_size, v_rms_eps=v.rms_norm_eps,
+        v_ln_eps=v.merger_ln_eps, v_use_bias=int(v.use_bias), v_post_norm=int(v.post_norm),
+        max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches,
+        max_prefill_tokens=max_prefill_tokens)
+
+
+def _i32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _i64p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class Engine:
+    """One GPU, one HIP stream, one model replica."""
+
+    def __init__(self, cfg: DotsConfig, device: int = 0, max_batch: int = 8, max_seq_len: int = 8192,
+                 max_patches: int = 8 * 19824 + 64, max_prefill_tokens: Optional[int] = None):
+        self.lib = _lib.load()
+        _prototypes(self.lib)
+        self.cfg = cfg
+        self.device = device
+        self.max_batch = max_batch
+        self.max_seq_len = max_seq_len
+        self.max_patches = max_patches
+        if max_prefill_tokens is None:
+            max_prefill_tokens = max_batch * max_seq_len
+        self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens)
+        h = C.c_void_p()
+        rc = self.lib.dots_create(C.byref(self._cc), device, C.byref(h))
+        if rc != 0:
+            raise DotsEngineError(f"dots_create failed ({rc}): {self.lib.dots_last_error(None).decode()}")
+        self.h = h
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise DotsEngineError(f"{what} failed ({rc}): {self.lib.dots_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dots_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.dots_stream(self.h) or 0)
+
+    def synchronize(self):
+        self._ck(self.lib.dots_synchronize(self.h), "dots_synchronize")
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, "torch.Tensor"]):  # noqa: F821 (torch only used by the caller)
+        import torch
+        dt = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32, torch.float16: DTYPE_F16}
+        for name, t in sd.items():
+            t = t.detach().cpu().contiguous()
+            if t.dtype not in dt:
+                t = t.float()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            self._ck(self.lib.dots_load_weight(self.h, name.encode(), C.c_void_p(t.data_ptr()), dt[t.dtype], shape, t.dim()),
+                     f"dots_load_weight({name})")
+        self._ck(self.lib.dots_finalize_weights(self.h), "dots_finalize_weights")
+
+    # ------------------------------------------------------------------ device memory helpers
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._ck(self.lib.dots_dev_alloc(self.h, nbytes, C.byref(p)), "dots_dev_alloc")
+        return int(p.value)
+
+    def dev_free(self, ptr: int):
+        self._ck(self.lib.dots_dev_free(self.h, C.c_void_p(ptr)), "dots_dev_free")
+
+    def to_device(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        p = self.dev_alloc(a.nbytes)
+        self._ck(self.lib.dots_memcpy_h2d(self.h, C.c_void_p(p), a.ctypes.data_as(C.c_void_p), a.nbytes), "dots_memcpy_h2d")
+        return p
+
+    def to_host(self, ptr: int, shape: Sequence[int], dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._ck(self.lib.dots_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes), "dots_memcpy_d2h")
+        return out
+
+    # ------------------------------------------------------------------ hot path
+    def vit_forward(self, pixel_values, grid_thw: np.ndarray, on_device: bool = False, out_dev: int = 0) -> int:
+        """pixel_values: np.float32 [N, patch_dim] (host) or a device pointer when on_device."""
+        grid = np.ascontiguousarray(grid_thw, dtype=np.int64)
+        n = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+        if on_device:
+            ptr = C.c_void_p(int(pixel_values))
+        else:
+            pv = np.ascontiguousarray(pixel_values, dtype=np.float32)
+            assert pv.shape[0] == n, (pv.shape, n)
+            ptr = pv.ctypes.data_as(C.c_void_p)
+        self._ck(self.lib.dots_vit_forward(self.h, ptr, int(on_device), n, _i64p(grid), grid.shape[0],
+                                           C.c_void_p(out_dev) if out_dev else None), "dots_vit_forward")
+        return n // (self.cfg.vision.spatial_merge_size ** 2)
+
+    def prefill(self, input_ids: np.ndarray, prompt_lens: np.ndarray):
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        lens = np.ascontiguousarray(prompt_lens, dtype=np.int32)
+        assert ids.shape[0] == int(lens.sum())
+        self._ck(self.lib.dots_prefill(self.h, _i32p(ids), _i32p(lens), lens.shape[0]), "dots_prefill")
+        self._B = int(lens.shape[0])
+
+    def decode_step(self):
+        self._ck(self.lib.dots_decode_step(self.h), "dots_decode_step")
+
+    def get_logits(self) -> np.ndarray:
+        out = np.empty((self._B, self.cfg.vocab_size), dtype=np.float32)
+        self._ck(self.lib.dots_get_logits(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "dots_get_logits")
+        return out
+
+    def get_last_tokens(self) -> np.ndarray:
+        out = np.empty((self._B,), dtype=np.int32)
+        self._ck(self.lib.dots_get_last_tokens(self.h, _i32p(out)), "dots_get_last_tokens")
+        return out
+
+    def set_next_tokens(self, tokens: Sequence[int]):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        self._ck(self.lib.dots_set_next_tokens(self.h, _i32p(t), t.shape[0]), "dots_set_next_tokens")
+
+    def generate(self, input_ids: np.ndarray, prompt_lens: np.ndarray, pixel_values=None,
+                 grid_thw: Optional[np.ndarray] = None, max_new_tokens: int = 128, eos_ids: Sequence[int] = (),
+                 pixel_on_device: bool = False):
+        """Packed prompts + packed patches -> (out_ids [B, max_new_tokens] int32, out_lens [B])."""
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        lens = np.ascontiguousarray(prompt_lens, dtype=np.int32)
+        B = int(lens.shape[0])
+        assert ids.shape[0] == int(lens.sum())
+        out_ids = np.zeros((B, max_new_tokens), dtype=np.int32)
+        out_lens = np.zeros((B,), dtype=np.int32)
+        eos = np.ascontiguousarray(list(eos_ids), dtype=np.int32)
+        if grid_thw is not None and len(grid_thw):
+            grid = np.ascontiguousarray(grid_thw, dtype=np.int64)
+            n = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+            if pixel_on_device:
+                ptr = C.c_void_p(int(pixel_values))
+            else:
+                pv = np.ascontiguousarray(pixel_values, dtype=np.float32)
+                assert pv.shape[0] == n
+                ptr = pv.ctypes.data_as(C.c_void_p)
+            gp, n_img = _i64p(grid), grid.shape[0]
+        else:
+            ptr, n, gp, n_img = None, 0, None, 0
+        self._ck(self.lib.dots_generate(self.h, _i32p(ids), _i32p(lens), B, ptr, int(pixel_on_device), n, gp, n_img,
+                                        max_new_tokens, _i32p(eos) if len(eos) else None, len(eos),
+                                        _i32p(out_ids), _i32p(out_lens)), "dots_generate")
+        self._B = B
+        return out_ids, out_lens
+
+    def stats(self) -> dict:
+        st = CDotsStats()
+        self._ck(self.lib.dots_get_stats(self.h, C.byref(st)), "dots_get_stats")
+        return {k: getattr(st, k) for k, _ in CDotsStats._fields_}
+
+    # ------------------------------------------------------------------ single kernels (device pointers)
+    def op_rmsnorm(self, x, w, y, rows, dim, eps):
+        self._ck(self.lib.dots_op_rmsnorm(self.h, x, w, y, rows, dim, eps), "dots_op_rmsnorm")
+
+    def op_layernorm(self, x, w, b, y, rows, dim, eps):
+        self._ck(self.lib.dots_op_layernorm(self.h, x, w, b, y, rows, dim, eps), "dots_op_layernorm")
+
+    def op_gemm(self, A, W, bias, residual, Cout, M, N, K, epilogue=EPI_NONE):
+        self._ck(self.lib.dots_op_gemm(self.h, A, W, bias or None, residual or None, Cout, M, N, K, epilogue), "dots_op_gemm")
+
+    def op_flash_attn(self, q, k, vt, out, cu_seqlens, Hq, Hkv, causal, scale):
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        self._ck(self.lib.dots_op_flash_attn(self.h, q, k, vt, out, _i32p(cu), cu.shape[0] - 1, Hq, Hkv, int(causal), scale),
+                 "dots_op_flash_attn")
+
+    def op_qkv_rope_split(self, qkv, q, k, vt, cu_seqlens, pos, Hq, Hkv, rope2d, theta):
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self._ck(self.lib.dots_op_qkv_rope_split(self.h, qkv, q, k, vt, _i32p(cu), cu.shape[0] - 1, _i32p(pos), Hq, Hkv,
+                                                 int(rope2d), theta), "dots_op_qkv_rope_split")
+
+    def op_gemm_skinny(self, X, W, out, M, N, K):
+        self._ck(self.lib.dots_op_gemm_skinny(self.h, X, W, out, M, N, K), "dots_op_gemm_skinny")

@@ -1,0 +1,162 @@
+/* dots_ocr_hip.h — C ABI of the MI355X-native dots.ocr inference engine (libdots_ocr_hip.so).
+ *
+ * The reference (rednote-hilab/dots.ocr) has NO native layer: its hot path is the three HF
+ * objects used in DotsOCRParser._inference_with_hf (dots_ocr/parser.py:78-117):
+ *     self.model.generate(**inputs, max_new_tokens=...)         parser.py:110
+ *     self.processor(...) / apply_chat_template / batch_decode  parser.py:93-105,114-116
+ *     AutoModelForCausalLM.from_pretrained(...)                 parser.py:68-74
+ * This header is the boundary a native binding for that path binds instead:
+ * plain pointers and sizes, opaque handle, int status codes, no exceptions, no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DOTS_E_* code on failure; the message is
+ *     available from dots_last_error(handle) (or dots_last_error(NULL) for create failures);
+ *   - the caller owns every buffer it passes; the engine owns all device memory it allocates;
+ *   - one handle = one GPU = one HIP stream.  A handle is NOT thread-safe; different handles
+ *     may be driven from different threads/processes (one per GPU);
+ *   - pointers named *_dev are device pointers on the handle's GPU, *_host are host pointers;
+ *     parameters named `x` with a companion `x_on_device` flag accept either;
+ *   - bf16 tensors are raw uint16_t.
+ */
+#ifndef DOTS_OCR_HIP_H
+#define DOTS_OCR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOTS_OK 0
+#define DOTS_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define DOTS_E_HIP (-2)       /* HIP runtime error */
+#define DOTS_E_STATE (-3)     /* call order (weights missing, sequence not prefetched, ...) */
+#define DOTS_E_CAPACITY (-4)  /* exceeds max_batch / max_seq_len / workspace */
+
+#define DOTS_DTYPE_BF16 0
+#define DOTS_DTYPE_F32 1
+#define DOTS_DTYPE_F16 2
+
+typedef struct DotsEngine DotsEngine;
+
+/* Mirrors the checkpoint's config.json (+ vision_config) that from_pretrained reads
+ * (parser.py:68-74).  Nothing is hard-coded in the kernels except head_dim == 128. */
+typedef struct DotsConfig {
+    /* language model (Qwen2 architecture) */
+    int32_t hidden_size, num_layers, num_heads, num_kv_heads, head_dim, intermediate_size, vocab_size;
+    float rope_theta, rms_norm_eps;
+    int32_t attention_bias;
+    int32_t image_token_id;
+    /* vision tower (NaViT) + patch merger */
+    int32_t v_embed_dim, v_layers, v_heads, v_intermediate, v_patch, v_merge, v_channels, v_temporal_patch;
+    float v_rms_eps, v_ln_eps;
+    int32_t v_use_bias, v_post_norm;
+    /* runtime capacity */
+    int32_t max_batch;        /* sequences decoded together (<= 64) */
+    int32_t max_seq_len;      /* prompt + generated tokens per sequence */
+    int64_t max_patches;      /* vision patches per dots_vit_forward call (workspace) */
+    int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
+} DotsConfig;
+
+/* Per-phase device time of the last dots_generate / dots_vit_forward / ... call, measured with
+ * HIP events on the engine's stream (what bench.py's roofline legs read). */
+typedef struct DotsStats {
+    float vit_ms, prefill_ms, decode_ms, total_ms;
+    float vit_attn_ms;        /* sum of the ViT flash-attention launches */
+    int32_t vit_attn_launches;
+    float vit_gemm_ms;        /* sum of the ViT GEMM launches */
+    int32_t decode_steps;
+    int64_t vit_patches, prefill_tokens, new_tokens;
+    double vit_attn_flops;    /* algorithmic: 4*N_i^2*E per layer summed over images */
+    double vit_flops;         /* SURVEY §8(d) ViT formula */
+    double prefill_flops;
+    double decode_bytes;      /* steps*W + sum ctx*kv_bytes_per_token */
+} DotsStats;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int dots_create(const DotsConfig* cfg, int device, DotsEngine** out);
+void dots_destroy(DotsEngine* e);
+const char* dots_last_error(DotsEngine* e);
+/* HIP stream of the handle (hipStream_t as void*), for callers that record their own events. */
+void* dots_stream(DotsEngine* e);
+
+/* One call per checkpoint tensor, named as in the HF state dict the reference loads
+ * (parser.py:68-74).  `data` is a host pointer; dtype bf16/f16/f32 (converted to bf16). */
+int dots_load_weight(DotsEngine* e, const char* name, const void* data_host, int dtype,
+                     const int64_t* shape, int ndim);
+/* Verifies every tensor the config requires is present, builds fused/packed device copies. */
+int dots_finalize_weights(DotsEngine* e);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* Replaces DotsVisionTransformer.forward(pixel_values, grid_thw) (HF-hub modeling_dots_vision.py,
+ * called inside model.generate at parser.py:110).  pixel_values f32 [total_patches, C*T*P*P],
+ * grid_thw int64 [n_img,3] (host).  out_embeds_dev: bf16 [total_patches/merge^2, hidden] or NULL
+ * (result then stays in the engine for the following dots_prefill). */
+int dots_vit_forward(DotsEngine* e, const float* pixel_values, int pixel_values_on_device,
+                     int64_t total_patches, const int64_t* grid_thw_host, int n_img,
+                     void* out_embeds_dev);
+
+/* Replaces prepare_inputs_embeds + the prefill forward of Qwen2ForCausalLM.
+ * Packed prompts: input_ids int32 [sum(prompt_lens)] (host), slot i of the batch gets prompt i.
+ * Vision rows from the preceding dots_vit_forward are scattered at image_token_id positions. */
+int dots_prefill(DotsEngine* e, const int32_t* input_ids_host, const int32_t* prompt_lens_host, int B);
+
+/* One greedy decode step for the B prefilled sequences. */
+int dots_decode_step(DotsEngine* e);
+
+/* Replaces model.generate(**inputs, max_new_tokens=N) with do_sample=False (parser.py:110):
+ * ViT over all images, prefill, greedy decode until every sequence hit an EOS id or N tokens.
+ * out_ids int32 [B, max_new_tokens] (host, new tokens only), out_lens int32 [B].
+ * n_eos == 0 disables EOS (fixed-length timing runs). */
+int dots_generate(DotsEngine* e, const int32_t* input_ids_host, const int32_t* prompt_lens_host, int B,
+                  const float* pixel_values, int pixel_values_on_device, int64_t total_patches,
+                  const int64_t* grid_thw_host, int n_img, int max_new_tokens,
+                  const int32_t* eos_ids_host, int n_eos, int32_t* out_ids_host, int32_t* out_lens_host);
+
+/* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
+int dots_get_logits(DotsEngine* e, float* out_host);
+/* Teacher forcing for per-step logit comparisons: overwrite the token the next decode step feeds. */
+int dots_set_next_tokens(DotsEngine* e, const int32_t* tokens_host, int B);
+/* Tokens chosen by the most recent prefill/decode step, int32 [B]. */
+int dots_get_last_tokens(DotsEngine* e, int32_t* out_host);
+int dots_get_stats(DotsEngine* e, DotsStats* out);
+int dots_synchronize(DotsEngine* e);
+
+/* ---- device memory helpers (so a binding needs no other GPU library) ------------------- */
+int dots_dev_alloc(DotsEngine* e, int64_t bytes, void** out_dev);
+int dots_dev_free(DotsEngine* e, void* dev);
+int dots_memcpy_h2d(DotsEngine* e, void* dst_dev, const void* src_host, int64_t bytes);
+int dots_memcpy_d2h(DotsEngine* e, void* dst_host, const void* src_dev, int64_t bytes);
+
+/* ---- single-kernel entry points (parity tests call the kernels through these) ---------- */
+/* y = rmsnorm(x) * w : bf16 [rows, dim]; fp32 statistics; two roundings as modeling_qwen2.py:246-252 */
+int dots_op_rmsnorm(DotsEngine* e, const void* x_dev, const void* w_dev, void* y_dev, int64_t rows, int dim, float eps);
+int dots_op_layernorm(DotsEngine* e, const void* x_dev, const void* w_dev, const void* b_dev, void* y_dev,
+                      int64_t rows, int dim, float eps);
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias): bf16 in, fp32 accumulate.
+ * epilogue: 0 none, 1 += residual (bf16 [M,N], may alias C), 2 SwiGLU (W rows interleaved in
+ * 32-row gate/up groups, C is [M,N/2]), 3 exact GELU, 4 fp32 output. */
+int dots_op_gemm(DotsEngine* e, const void* A_dev, const void* W_dev, const void* bias_dev,
+                 const void* residual_dev, void* C_dev, int64_t M, int N, int K, int epilogue);
+/* Flash attention over packed sequences.  q [Hq, T, 128], k [Hkv, T, 128] bf16 (head-major),
+ * vt [Hkv, 128, Tpad] (V transposed, every sequence padded to 64 keys, keys permuted inside
+ * 16-groups as csrc/attn_prefill.hip documents), cu_seqlens int32 [n_seq+1] (host).
+ * out bf16 [T, Hq*128]. */
+int dots_op_flash_attn(DotsEngine* e, const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                       const int32_t* cu_seqlens_host, int n_seq, int Hq, int Hkv, int causal, float scale);
+/* Splits a packed qkv GEMM output [T, (Hq+2*Hkv)*128] into rope'd q/k and transposed v in the
+ * layouts dots_op_flash_attn consumes.  rope2d != 0: vision 2-D rope from pos [T,2] int32;
+ * else 1-D rope with positions pos [T] int32 and base theta. */
+int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv_dev, void* q_dev, void* k_dev, void* vt_dev,
+                           const int32_t* cu_seqlens_host, int n_seq, const int32_t* pos_host,
+                           int Hq, int Hkv, int rope2d, float theta);
+/* Skinny decode GEMM: out f32 [16, N] = X[16 (M valid), K] @ W[N,K]^T  (split-K reduced). */
+int dots_op_gemm_skinny(DotsEngine* e, const void* X_dev, const void* W_dev, void* out_f32_dev, int M, int N, int K);
+
+/* MFMA fragment-layout / LDS-DMA probe (csrc/probe_mfma.hip; tests/test_mfma_layout.py). */
+int dots_probe_mfma(int which, const void* A, const void* Bt, void* D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOTS_OCR_HIP_H */

@@ -1,0 +1,232 @@
+"""Parity of every HIP kernel against the CPU oracle, through the C ABI (needs an MI355X).
+
+Tolerances: the kernels accumulate in fp32 and round once to bf16 where the oracle's
+emulate_bf16 mode rounds, so results may differ by accumulation order only:  <= 1 bf16 ulp of
+the output magnitude (2^-8 relative) plus a small absolute floor.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from dots_ocr_amd.config import DotsConfig
+    from dots_ocr_amd.engine import Engine
+    e = Engine(DotsConfig.tiny(), max_batch=4, max_seq_len=512, max_patches=4096, max_prefill_tokens=2048)
+    yield e
+    e.close()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def dev(x):
+    return x.cuda().contiguous()
+
+
+def close(got, ref, rel=2 ** -7, abs_=1e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = rel * ref.abs() + abs_ * max(1.0, float(ref.abs().max()))
+    bad = err > tol
+    assert not bad.any(), f"max err {err.max():.5f} (ref max {ref.abs().max():.4f}), {int(bad.sum())} / {bad.numel()} out of tolerance"
+
+
+def run(eng, fn, *a):
+    torch.cuda.synchronize()
+    fn(*a)
+    eng.synchronize()
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 256), (37, 768), (513, 1536), (5, 4096)])
+def test_rmsnorm(eng, rows, dim):
+    g = torch.Generator().manual_seed(rows)
+    x = bf(torch.randn(rows, dim, generator=g) * 3)
+    w = bf(1 + 0.1 * torch.randn(dim, generator=g))
+    xd, wd, yd = dev(x), dev(w), torch.empty(rows, dim, dtype=torch.bfloat16, device="cuda")
+    run(eng, eng.op_rmsnorm, xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), rows, dim, 1e-5)
+    close(yd, om.rms_norm(x.float(), w.float(), 1e-5, True), rel=2 ** -7)
+
+
+@pytest.mark.parametrize("rows,dim", [(3, 256), (130, 1536)])
+def test_layernorm(eng, rows, dim):
+    g = torch.Generator().manual_seed(rows)
+    x = bf(torch.randn(rows, dim, generator=g) * 2 + 0.5)
+    w = bf(1 + 0.1 * torch.randn(dim, generator=g))
+    b = bf(0.1 * torch.randn(dim, generator=g))
+    xd, wd, bd, yd = dev(x), dev(w), dev(b), torch.empty(rows, dim, dtype=torch.bfloat16, device="cuda")
+    run(eng, eng.op_layernorm, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), rows, dim, 1e-6)
+    close(yd, om.layer_norm(x.float(), w.float(), b.float(), 1e-6, True))
+
+
+def _pack_w13(gate, up):
+    I, K = gate.shape
+    return torch.stack([gate.view(I // 32, 32, K), up.view(I // 32, 32, K)], dim=1).reshape(2 * I, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 256, 128), (1000, 384, 640), (129, 1536, 1536), (4097, 128, 4224)])
+@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+def test_gemm(eng, M, N, K, epi):
+    from dots_ocr_amd import engine as E
+    g = torch.Generator().manual_seed(M * 7 + N + epi)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = bf(torch.randn(N, generator=g))
+    R = bf(torch.randn(M, N, generator=g))
+    ref = A.float() @ W.float().t() + bias.float()
+    if epi == E.EPI_RESIDUAL:
+        ref = ref + R.float()
+    if epi == E.EPI_GELU:
+        ref = torch.nn.functional.gelu(ref)
+    Ad, Wd, bd, Rd = dev(A), dev(W), dev(bias), dev(R)
+    out = torch.empty(M, N, dtype=torch.float32 if epi == E.EPI_F32 else torch.bfloat16, device="cuda")
+    run(eng, eng.op_gemm, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), Rd.data_ptr() if epi == E.EPI_RESIDUAL else 0,
+        out.data_ptr(), M, N, K, epi)
+    if epi == E.EPI_F32:
+        close(out, ref, rel=1e-4, abs_=1e-4)
+    else:
+        close(out, bf(ref))
+    # transpose detection: the reference is not symmetric
+    if M == N:
+        assert (out.float().cpu() - ref.t()).abs().max() > 0.1
+
+
+def test_gemm_residual_in_place_and_no_bias(eng):
+    from dots_ocr_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 333, 256, 192
+    A, W, R = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.1), bf(torch.randn(M, N, generator=g))
+    Ad, Wd, Rd = dev(A), dev(W), dev(R)
+    run(eng, eng.op_gemm, Ad.data_ptr(), Wd.data_ptr(), 0, Rd.data_ptr(), Rd.data_ptr(), M, N, K, E.EPI_RESIDUAL)
+    close(Rd, bf(R.float() + A.float() @ W.float().t()))
+
+
+@pytest.mark.parametrize("M,I,K", [(70, 64, 128), (515, 512, 256)])
+def test_gemm_swiglu(eng, M, I, K):
+    from dots_ocr_amd import engine as E
+    g = torch.Generator().manual_seed(M)
+    A = bf(torch.randn(M, K, generator=g))
+    gate, up = bf(torch.randn(I, K, generator=g) / math.sqrt(K)), bf(torch.randn(I, K, generator=g) / math.sqrt(K))
+    W13 = _pack_w13(gate, up)
+    ref = torch.nn.functional.silu(A.float() @ gate.float().t()) * (A.float() @ up.float().t())
+    Ad, Wd = dev(A), dev(W13)
+    out = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
+    run(eng, eng.op_gemm, Ad.data_ptr(), Wd.data_ptr(), 0, 0, out.data_ptr(), M, 2 * I, K, E.EPI_SWIGLU)
+    close(out, bf(ref))
+
+
+def _vt_reference(v, lens):
+    """v [T, H, 128] -> V^T [H, 128, Tpad] with the kernel's padding and 16-key group order."""
+    H = v.shape[1]
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    outs, t0 = [], 0
+    for n in lens:
+        npad = (n + 63) // 64 * 64
+        vp = torch.zeros(npad, H, 128)
+        vp[:n] = v[t0:t0 + n]
+        idx = (torch.arange(npad) // 16 * 16).view(-1, 16)[:, 0:1] + perm.view(1, 16)       # position p holds key perm[p]
+        outs.append(vp[idx.reshape(-1)])
+        t0 += n
+    return torch.cat(outs, 0).permute(1, 2, 0).contiguous()
+
+
+def _attn_case(eng, lens, Hq, Hkv, causal, rope2d, seed):
+    g = torch.Generator().manual_seed(seed)
+    T = sum(lens)
+    NQ = (Hq + 2 * Hkv) * 128
+    qkv = bf(torch.randn(T, NQ, generator=g))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    Tpad = sum((n + 63) // 64 * 64 for n in lens)
+    if rope2d:
+        pos = torch.stack([torch.randint(0, 40, (T,), generator=g), torch.randint(0, 40, (T,), generator=g)], -1)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float) / 64))
+        fr = (pos.float().unsqueeze(-1) * inv).flatten(1)
+        theta = 10000.0
+    else:
+        pos = torch.cat([torch.arange(n) for n in lens])
+        inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))
+        fr = pos.float().unsqueeze(-1) * inv
+        theta = 1e6
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().unsqueeze(1), emb.sin().unsqueeze(1)
+    x = qkv.float()
+    q = x[:, :Hq * 128].view(T, Hq, 128)
+    k = x[:, Hq * 128:(Hq + Hkv) * 128].view(T, Hkv, 128)
+    v = x[:, (Hq + Hkv) * 128:].view(T, Hkv, 128)
+    q_ref = bf(q * cos + om.rotate_half(q) * sin).float()
+    k_ref = bf(k * cos + om.rotate_half(k) * sin).float()
+
+    qd = torch.zeros(Hq, T, 128, dtype=torch.bfloat16, device="cuda")
+    kd = torch.zeros(Hkv, T + 64, 128, dtype=torch.bfloat16, device="cuda")[:, :T]      # spare rows after the end
+    kd = torch.zeros(Hkv * (T + 64) * 128, dtype=torch.bfloat16, device="cuda")
+    vtd = torch.full((Hkv, 128, Tpad), 7.0, dtype=torch.bfloat16, device="cuda")
+    qkvd = dev(qkv)
+    run(eng, eng.op_qkv_rope_split, qkvd.data_ptr(), qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), cu,
+        pos.numpy().astype(np.int32), Hq, Hkv, rope2d, theta)
+    k_got = kd[: Hkv * T * 128].view(Hkv, T, 128)
+    close(qd.permute(1, 0, 2), q_ref, rel=2 ** -7, abs_=2e-3)
+    close(k_got.permute(1, 0, 2), k_ref, rel=2 ** -7, abs_=2e-3)
+    assert torch.equal(vtd.float().cpu(), _vt_reference(v, lens))
+
+    out = torch.zeros(T, Hq * 128, dtype=torch.bfloat16, device="cuda")
+    scale = 1 / math.sqrt(128)
+    run(eng, eng.op_flash_attn, qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), cu, Hq, Hkv, causal, scale)
+    ref = torch.empty(T, Hq, 128)
+    t0 = 0
+    rep = Hq // Hkv
+    for n in lens:
+        ref[t0:t0 + n] = om._attention(q_ref[t0:t0 + n].transpose(0, 1),
+                                       k_ref[t0:t0 + n].transpose(0, 1).repeat_interleave(rep, 0),
+                                       v[t0:t0 + n].transpose(0, 1).repeat_interleave(rep, 0), scale, causal, True).transpose(0, 1)
+        t0 += n
+    close(out.view(T, Hq, 128), ref, rel=2 ** -6, abs_=4e-3)
+
+
+@pytest.mark.parametrize("lens", [[64], [200, 64, 1, 333], [128, 129, 127], [1000]])
+def test_vision_rope_split_and_flash_attn(eng, lens):
+    _attn_case(eng, lens, 2, 2, False, True, seed=sum(lens))
+
+
+@pytest.mark.parametrize("lens", [[130, 77], [64, 65, 1], [700]])
+def test_lm_rope_split_and_causal_gqa_flash_attn(eng, lens):
+    _attn_case(eng, lens, 6, 1, True, False, seed=sum(lens) + 1)
+
+
+def test_flash_attn_online_softmax_rescale_branch(eng):
+    """A key far above the rest arriving in a LATE tile forces the running-max rescale (guide §5.4 rule 26)."""
+    g = torch.Generator().manual_seed(11)
+    n, H = 300, 2
+    q = bf(torch.randn(n, H, 128, generator=g))
+    k = bf(torch.randn(n, H, 128, generator=g))
+    v = bf(torch.randn(n, H, 128, generator=g))
+    k[250] = bf(q[7] * 4)                  # spike for query 7 in the 4th tile
+    cu = np.array([0, n], np.int32)
+    qd = dev(q.permute(1, 0, 2))
+    kd = torch.zeros(H * (n + 64) * 128, dtype=torch.bfloat16, device="cuda")
+    kd[: H * n * 128] = dev(k.permute(1, 0, 2)).reshape(-1)
+    vtd = dev(bf(_vt_reference(v.float(), [n])))
+    out = torch.zeros(n, H * 128, dtype=torch.bfloat16, device="cuda")
+    scale = 1 / math.sqrt(128)
+    run(eng, eng.op_flash_attn, qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), cu, H, H, False, scale)
+    ref = om._attention(q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1), scale, False, True)
+    close(out.view(n, H, 128), ref.transpose(0, 1), rel=2 ** -6, abs_=4e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (8, 256, 768), (16, 1024, 1536), (5, 1536, 8960)])
+def test_gemm_skinny(eng, M, N, K):
+    g = torch.Generator().manual_seed(N + M)
+    X = torch.zeros(16, K)
+    X[:M] = torch.randn(M, K, generator=g)
+    X, W = bf(X), bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    Xd, Wd = dev(X), dev(W)
+    out = torch.zeros(16, N, dtype=torch.float32, device="cuda")
+    run(eng, eng.op_gemm_skinny, Xd.data_ptr(), Wd.data_ptr(), out.data_ptr(), M, N, K)
+    close(out[:M], X[:M].float() @ W.float().t(), rel=1e-4, abs_=1e-4)
