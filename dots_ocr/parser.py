@@ -1,0 +1,2 @@
+"""`dots_ocr.parser` (reference dots_ocr/parser.py) served by the MI355X engine."""
+from dots_ocr_amd.parser import DotsOCRParser  # noqa: F401

@@ -1,0 +1,2 @@
+from dots_ocr_amd.prompts import *  # noqa: F401,F403
+from dots_ocr_amd.prompts import dict_promptmode_to_prompt  # noqa: F401

@@ -1,0 +1,127 @@
+"""``DotsOcrHipForCausalLM`` — the object DotsOCRParser installs as ``self.model``.
+
+It honours the one model call the reference makes, ``self.model.generate(**inputs,
+max_new_tokens=...) -> LongTensor[B, T+n]`` (dots_ocr/parser.py:110; demo/demo_hf.py:44), and the
+``from_pretrained`` entry of parser.py:68-74, but everything underneath is the HIP engine: ViT,
+merger, prefill and the hipGraph'd greedy decode loop run inside ``dots_generate`` on one GPU.
+
+Greedy decoding only (``do_sample=False``): sampling at temperature is a SURVEY §8(f) "next" row.
+There is no CPU fallback — constructing the model without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .config import DotsConfig
+from .engine import Engine
+from .weights import load_state_dict, random_state_dict
+
+
+class DotsOcrHipForCausalLM:
+    def __init__(self, cfg: DotsConfig, state_dict, device: int = 0, max_batch: int = 8, max_seq_len: int = 8192,
+                 max_patches: Optional[int] = None):
+        self.config = cfg
+        self.device_index = device
+        max_patches = max_patches or max(max_batch * 19824 + 64, 57600 + 64)
+        self.engine = Engine(cfg, device=device, max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches)
+        self.engine.load_state_dict(state_dict)
+        self.max_batch = max_batch
+        self.max_seq_len = max_seq_len
+        self.generation_config = {"do_sample": False, "eos_token_id": list(cfg.eos_token_ids), "pad_token_id": cfg.pad_token_id}
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_pretrained(cls, model_path, device_map=None, torch_dtype=None, attn_implementation=None,
+                        trust_remote_code=None, device: Optional[int] = None, **kw):
+        """Accepts (and ignores) the HF keyword arguments the reference passes at parser.py:68-74."""
+        model_path = Path(model_path)
+        cfg = DotsConfig.from_pretrained(model_path)
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        return cls(cfg, load_state_dict(model_path), device=device, **kw)
+
+    @classmethod
+    def from_random(cls, cfg: Optional[DotsConfig] = None, seed: int = 0, device: int = 0, **kw):
+        cfg = cfg or DotsConfig()
+        return cls(cfg, random_state_dict(cfg, seed=seed), device=device, **kw)
+
+    def eval(self):
+        return self
+
+    @property
+    def device(self):
+        import torch
+        return torch.device("cuda", self.device_index)
+
+    # ------------------------------------------------------------------ generate
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
+                 max_new_tokens: int = 128, do_sample: bool = False, eos_token_id=None, pad_token_id=None, **_):
+        """HF-shaped greedy generate.  Returns LongTensor [B, T + n]: the (padded) prompt followed by the new
+        tokens, positions after a sequence's EOS filled with pad_token_id."""
+        import torch
+        if do_sample:
+            raise NotImplementedError("the HIP engine decodes greedily (do_sample=False)")
+        ids = input_ids.detach().cpu().numpy()
+        B, T = ids.shape
+        mask = attention_mask.detach().cpu().numpy().astype(bool) if attention_mask is not None else np.ones_like(ids, bool)
+        eos = self.config.eos_token_ids if eos_token_id is None else eos_token_id
+        eos = [eos] if isinstance(eos, int) else list(eos)
+        pad = self.config.pad_token_id if pad_token_id is None else pad_token_id
+        grid = image_grid_thw.detach().cpu().numpy().astype(np.int64) if image_grid_thw is not None else np.zeros((0, 3), np.int64)
+        merge2 = self.config.vision.spatial_merge_size ** 2
+
+        # which images belong to which sequence: image tokens are consumed in order
+        prompts = [ids[b][mask[b]].astype(np.int32) for b in range(B)]
+        n_img_tok = [int((p == self.config.image_token_id).sum()) for p in prompts]
+        per_img_tok = (grid[:, 0] * grid[:, 1] * grid[:, 2] // merge2).tolist()
+        img_of_seq, gi = [], 0
+        for b in range(B):
+            need, lst = n_img_tok[b], []
+            while need > 0:
+                if gi >= len(per_img_tok):
+                    raise ValueError("image tokens do not match image_grid_thw")
+                need -= per_img_tok[gi]
+                lst.append(gi)
+                gi += 1
+            if need != 0:
+                raise ValueError("image tokens do not match image_grid_thw")
+            img_of_seq.append(lst)
+        patch_off = np.concatenate([[0], np.cumsum(grid[:, 0] * grid[:, 1] * grid[:, 2])]).astype(np.int64)
+
+        pv_dev, pv_host = None, None
+        if pixel_values is not None:
+            if pixel_values.is_cuda:
+                pv_dev = pixel_values.contiguous().float()
+                torch.cuda.current_stream().synchronize()
+            else:
+                pv_host = np.ascontiguousarray(pixel_values.detach().numpy(), dtype=np.float32)
+
+        new_tokens = np.full((B, max_new_tokens), pad, dtype=np.int64)
+        n_max = 0
+        for s in range(0, B, self.max_batch):                       # static batches of <= max_batch sequences
+            sl = list(range(s, min(B, s + self.max_batch)))
+            imgs = [g for b in sl for g in img_of_seq[b]]
+            lens = np.array([len(prompts[b]) for b in sl], np.int32)
+            packed = np.concatenate([prompts[b] for b in sl])
+            if imgs:
+                lo, hi = int(patch_off[imgs[0]]), int(patch_off[imgs[-1] + 1])     # images of a slice are contiguous
+                if pv_dev is not None:
+                    pix, on_dev = pv_dev.data_ptr() + lo * pv_dev.shape[1] * 4, True
+                else:
+                    pix, on_dev = pv_host[lo:hi], False
+                out, out_lens = self.engine.generate(packed, lens, pix, grid[imgs[0]:imgs[-1] + 1], max_new_tokens, eos, on_dev)
+            else:
+                out, out_lens = self.engine.generate(packed, lens, None, None, max_new_tokens, eos)
+            for j, b in enumerate(sl):
+                new_tokens[b, :out_lens[j]] = out[j, :out_lens[j]]
+                n_max = max(n_max, int(out_lens[j]))
+        full = np.concatenate([ids.astype(np.int64), new_tokens[:, :n_max]], axis=1)    # HF stops at the longest sequence
+        res = torch.from_numpy(full)
+        return res.to(input_ids.device) if input_ids.is_cuda else res
+
+    def stats(self) -> dict:
+        return self.engine.stats()

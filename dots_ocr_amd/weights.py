@@ -73,23 +73,31 @@ def expected_tensors(cfg: DotsConfig) -> Dict[str, Tuple[int, ...]]:
     return t
 
 
+def _is_norm_scale(name: str) -> bool:
+    return name.endswith(("norm.weight", "norm1.weight", "norm2.weight", "layernorm.weight", "ln_q.weight"))
+
+
 def random_state_dict(cfg: DotsConfig, seed: int = 0, std: float = 0.02,
-                      dtype: torch.dtype = torch.bfloat16) -> Dict[str, torch.Tensor]:
+                      dtype: torch.dtype = torch.bfloat16, threads: int = 1) -> Dict[str, torch.Tensor]:
     """Seeded N(0, std) weights at the checkpoint's shapes; norm scales ~1, biases small.
-    Each tensor gets its own generator keyed by (seed, name) so the result does not depend on
-    dict order and a single tensor can be regenerated in isolation."""
-    out: Dict[str, torch.Tensor] = {}
-    for idx, (name, shape) in enumerate(expected_tensors(cfg).items()):
+    Each tensor gets its own generator keyed by (seed, index) so the result does not depend on
+    thread scheduling and a single tensor can be regenerated in isolation."""
+    items = list(expected_tensors(cfg).items())
+
+    def make(idx_name_shape):
+        idx, (name, shape) = idx_name_shape
         g = torch.Generator().manual_seed((seed * 1000003 + idx * 7919 + 17) % (2 ** 31))
-        if name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight") \
-                or name.endswith("layernorm.weight") or name.endswith("ln_q.weight"):
+        if _is_norm_scale(name):
             w = 1.0 + 0.1 * torch.randn(shape, generator=g)
-        elif name.endswith(".bias"):
-            w = std * torch.randn(shape, generator=g)
         else:
             w = std * torch.randn(shape, generator=g)
-        out[name] = w.to(dtype)
-    return out
+        return name, w.to(dtype)
+
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            return dict(ex.map(make, enumerate(items)))
+    return dict(map(make, enumerate(items)))
 
 
 # ---------------------------------------------------------------------- safetensors reader
