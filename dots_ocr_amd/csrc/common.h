@@ -16,15 +16,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 DEVI float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
-DEVI bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// f32 -> bf16, round-to-nearest-even.  The native __bf16 cast lowers to ONE v_cvt_pk_bf16_f32 on gfx950
+// (a software RNE with a NaN branch costs ~10 VALU + an exec-mask branch per element: measured as the
+// dominant VALU cost of the flash-attention loop in round 1).
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+DEVI bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+DEVI uint32_t pack_bf2(float lo, float hi) {
+    bf16x2_native v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
-
-DEVI uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 DEVI float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 DEVI float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

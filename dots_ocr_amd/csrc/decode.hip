@@ -23,6 +23,13 @@ namespace {
 constexpr int PAGE = 64;
 constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
 
+// Fragment-order operand layouts of the skinny (M <= 16) GEMMs: one 1 KiB chunk per MFMA operand,
+//   weights  Wd[(n_tile*(K/32) + kstep)*64 + lane][8],  lane = g*16 + i  <->  W[16*n_tile + i][32*kstep + 8g .. +7]
+//   inputs   Xf[kstep*64 + lane][8],                     lane = g*16 + m  <->  X[m][32*kstep + 8g .. +7]
+// so every wave-level load is one contiguous, fully used 1 KiB global_load_dwordx4 (8 cache lines per
+// instruction instead of 64 quarter-used sectors with row-major operands: measured 2.1 -> see profiles/).
+DEVI size_t frag_off(int m, int k) { return ((size_t)((k >> 5) * 64 + ((k >> 3) & 3) * 16 + m)) * 8 + (k & 7); }
+
 DEVI int k_chunk(int key, int d) { return ((key >> 4) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (key & 15); }
 DEVI int v_off(int key, int d) {
     const int kk = key & 31;
@@ -79,54 +86,59 @@ __global__ __launch_bounds__(256) void kv_to_pages_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Skinny GEMM: partial[s][m][n] = sum over K-slice s of X[m][k] * W[n][k], m < 16.
-// grid (N/64, S); wave = one 16-row weight tile; per 128-k group a lane reads 64 contiguous bytes of
-// its weight row as 4 x 16 B (MFMA j takes bytes 16j..16j+15 of every lane's run: the contraction
-// order inside the group is permuted identically for W and X, which a dot product does not care about).
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                          float* __restrict__ partial, int N, int K, int S) {
+// Skinny GEMM: partial[s][m][n] = sum over K-slice s of X[m][k] * W[n][k], m < 16, operands in
+// fragment order.  grid (ceil(N/64), S); wave = one 16-row weight tile streaming its K-slice straight
+// into the MFMA A operand, 8 chunks (8 KiB) in flight per wave, non-temporal (each byte is read once).
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ Xf, const bf16_t* __restrict__ Wd,
+                                                          float* __restrict__ partial, int N, int K, int S, int M) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = l & 15, g = l >> 4;
-    const int n0 = (blockIdx.x * 4 + w) * 16;
+    const int n_tile = blockIdx.x * 4 + w;
+    const int n0 = n_tile * 16;
     if (n0 >= N) return;
-    const int ngroups = K / 128;
+    const int KS = K / 32;
     const int s = blockIdx.y;
-    const int g0 = (int)((int64_t)s * ngroups / S), g1 = (int)((int64_t)(s + 1) * ngroups / S);
-    const bf16_t* wp = W + (size_t)(n0 + i) * K + g * 32;
-    const bf16_t* xp = X + (size_t)i * K + g * 32;
+    const int k0 = (int)((int64_t)s * KS / S), k1 = (int)((int64_t)(s + 1) * KS / S);
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + l;
+    const bf16x8* xp = reinterpret_cast<const bf16x8*>(Xf) + l;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    int kg = g0;
-    for (; kg + 1 < g1; kg += 2) {
+    int ks = k0;
+    for (; ks + 8 <= k1; ks += 8) {
         bf16x8 a[8], b[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)kg * 128 + j * 8));
-            a[4 + j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)(kg + 1) * 128 + j * 8));
-        }
+        for (int j = 0; j < 8; ++j) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            b[j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)kg * 128 + j * 8);
-            b[4 + j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)(kg + 1) * 128 + j * 8);
-        }
+        for (int j = 0; j < 8; ++j) b[j] = xp[(size_t)(ks + j) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; j += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4 + j], b[4 + j], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], b[j + 1], acc1, 0, 0, 0);
         }
     }
-    if (kg < g1) {
-        bf16x8 a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + (size_t)kg * 128 + j * 8));
-            b[j] = *reinterpret_cast<const bf16x8*>(xp + (size_t)kg * 128 + j * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
+    for (; ks < k1; ++ks) {
+        bf16x8 a = __builtin_nontemporal_load(wp + (size_t)ks * 64);
+        bf16x8 b = xp[(size_t)ks * 64];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
     }
     // D[n = 4g + r][m = i]  ->  partial[s][m][n0 + 4g .. +3]
     f32x4 r = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
-    *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;
+    if (i < M) *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;     // padding rows are never stored
+}
+
+// row-major [rows, K] -> fragment order (weights: rows = N, 16-row tiles; inputs: one 16-row tile)
+__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;          // destination 16-B chunk
+    const int KS = K / 32;
+    const int64_t tiles = (rows + 15) / 16;
+    if (c >= tiles * KS * 64) return;
+    const int lane = (int)(c & 63);
+    const int64_t t = c >> 6;
+    const int ks = (int)(t % KS);
+    const int64_t tile = t / KS;
+    const int64_t row = tile * 16 + (lane & 15);
+    u32x4 v = {0, 0, 0, 0};
+    if (row < rows) v = *reinterpret_cast<const u32x4*>(src + row * K + ks * 32 + (lane >> 4) * 8);
+    *reinterpret_cast<u32x4*>(dst + c * 8) = v;
 }
 
 __global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* __restrict__ partial, float* __restrict__ out,
@@ -139,94 +151,127 @@ __global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// h[b] = embed[tok[b]];  xn[b] = rmsnorm(h[b]) * w      (grid B, block 256)
-DEVI float block_sum_256(float v, float* red) {
+// Row kernels of the decode step.  One block per sequence row where a full-row statistic is needed
+// (rmsnorm); each thread owns 4 consecutive features so every partial-slab read is one 16-B load and
+// the S slab reads of a thread are independent (unrolled), not a dependent chain.
+constexpr int ROW_THREADS = 512;           // 512 x 4 features covers hidden <= 2048
+
+DEVI float block_sum(float v, float* red) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float t = red[0] + red[1] + red[2] + red[3];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_THREADS / 64; ++i) t += red[i];
     __syncthreads();
     return t;
 }
 
-__global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ embed,
-                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ h,
-                                                            bf16_t* __restrict__ xn, int dim, float eps) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    const bf16_t* src = embed + (size_t)tokens[b] * dim;
-    float ss = 0.f;
-    for (int d = threadIdx.x; d < dim; d += 256) {
-        const bf16_t v = src[d];
-        h[(size_t)b * dim + d] = v;
-        const float f = bf2f(v);
-        ss += f * f;
+DEVI f32x4 slab_sum4(const float* __restrict__ p, size_t stride, int S) {
+    f32x4 a = {0, 0, 0, 0};
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * stride);
+        f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * stride);
+        f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * stride);
+        a += (v0 + v1) + (v2 + v3);
     }
-    const float rstd = rsqrtf(block_sum_256(ss, red) / dim + eps);
-    for (int d = threadIdx.x; d < dim; d += 256)
-        xn[(size_t)b * dim + d] = f2bf(bf2f(f2bf(bf2f(src[d]) * rstd)) * bf2f(w[d]));
+    for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
+    return a;
 }
 
-// h[b] = bf16(h[b] + sum_s partial[s][b][:]);  xn[b] = rmsnorm(h[b]) * w
-__global__ __launch_bounds__(256) void reduce_residual_rmsnorm_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ h,
-                                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
-                                                                      int dim, float eps) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    float vals[8];
-    float ss = 0.f;
-    int c = 0;
-    for (int d = threadIdx.x; d < dim; d += 256, ++c) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += partial[((size_t)s * 16 + b) * dim + d];
-        const bf16_t hv = f2bf(bf2f(h[(size_t)b * dim + d]) + a);
-        h[(size_t)b * dim + d] = hv;
-        const float f = bf2f(hv);
-        vals[c] = f;
-        ss += f * f;
-    }
-    const float rstd = rsqrtf(block_sum_256(ss, red) / dim + eps);
-    c = 0;
-    for (int d = threadIdx.x; d < dim; d += 256, ++c)
-        xn[(size_t)b * dim + d] = f2bf(bf2f(f2bf(vals[c] * rstd)) * bf2f(w[d]));
+// 4 normalised features (m, k..k+3) -> fragment-order input buffer (8-byte store)
+DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, float a, float b, float c, float d) {
+    u32x2 pk = {pack_bf2(a, b), pack_bf2(c, d)};
+    *reinterpret_cast<u32x2*>(xf + frag_off(m, k)) = pk;
 }
 
-// act[b][j] = silu(sum_s P[s][b][gate(j)]) * sum_s P[s][b][up(j)], packed rows: group of 64 = 32 gate | 32 up
-__global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ act,
-                                                            int I, int B) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * I) return;
-    const int b = idx / I, j = idx - b * I;
+// h[b] = rows[b] (embedding row of tokens[b], or h_in[b] when tokens == nullptr);  xn = rmsnorm(h) * w (fragment order)
+__global__ __launch_bounds__(ROW_THREADS) void embed_rmsnorm_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ embed,
+                                                                    const bf16_t* __restrict__ w, bf16_t* __restrict__ h,
+                                                                    bf16_t* __restrict__ xn, int dim, float eps) {
+    __shared__ float red[ROW_THREADS / 64];
+    const int b = blockIdx.x, k = threadIdx.x * 4;
+    const bool on = k < dim;
+    float v[4] = {0, 0, 0, 0};
+    if (on) {
+        const bf16_t* src = tokens ? embed + (size_t)tokens[b] * dim : h + (size_t)b * dim;
+        u32x2 x = *reinterpret_cast<const u32x2*>(src + k);
+        v[0] = lo_bf(x[0]); v[1] = hi_bf(x[0]); v[2] = lo_bf(x[1]); v[3] = hi_bf(x[1]);
+        if (tokens) *reinterpret_cast<u32x2*>(h + (size_t)b * dim + k) = x;
+    }
+    const float rstd = rsqrtf(block_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3], red) / dim + eps);
+    if (on) {
+        u32x2 ww = *reinterpret_cast<const u32x2*>(w + k);
+        store_frag4(xn, b, k, bf2f(f2bf(v[0] * rstd)) * lo_bf(ww[0]), bf2f(f2bf(v[1] * rstd)) * hi_bf(ww[0]),
+                    bf2f(f2bf(v[2] * rstd)) * lo_bf(ww[1]), bf2f(f2bf(v[3] * rstd)) * hi_bf(ww[1]));
+    }
+}
+
+// h[b] = bf16(h[b] + sum_s partial[s][b][:]);  xn[b] = rmsnorm(h[b]) * w (fragment order)
+__global__ __launch_bounds__(ROW_THREADS) void reduce_residual_rmsnorm_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ h,
+                                                                              const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
+                                                                              int dim, float eps) {
+    __shared__ float red[ROW_THREADS / 64];
+    const int b = blockIdx.x, k = threadIdx.x * 4;
+    const bool on = k < dim;
+    float v[4] = {0, 0, 0, 0};
+    if (on) {
+        f32x4 a = slab_sum4(partial + (size_t)b * dim + k, (size_t)16 * dim, S);
+        u32x2 x = *reinterpret_cast<const u32x2*>(h + (size_t)b * dim + k);
+        u32x2 o = {pack_bf2(lo_bf(x[0]) + a[0], hi_bf(x[0]) + a[1]), pack_bf2(lo_bf(x[1]) + a[2], hi_bf(x[1]) + a[3])};
+        *reinterpret_cast<u32x2*>(h + (size_t)b * dim + k) = o;
+        v[0] = lo_bf(o[0]); v[1] = hi_bf(o[0]); v[2] = lo_bf(o[1]); v[3] = hi_bf(o[1]);
+    }
+    const float rstd = rsqrtf(block_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3], red) / dim + eps);
+    if (on) {
+        u32x2 ww = *reinterpret_cast<const u32x2*>(w + k);
+        store_frag4(xn, b, k, bf2f(f2bf(v[0] * rstd)) * lo_bf(ww[0]), bf2f(f2bf(v[1] * rstd)) * hi_bf(ww[0]),
+                    bf2f(f2bf(v[2] * rstd)) * lo_bf(ww[1]), bf2f(f2bf(v[3] * rstd)) * hi_bf(ww[1]));
+    }
+}
+
+// act[b][j..j+3] = silu(sum_s P[s][b][gate(j)]) * sum_s P[s][b][up(j)], packed rows: group of 64 = 32 gate | 32 up.
+// grid (ceil(I/4/256), B); output in fragment order (K = I) for the down projection.
+__global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ act, int I) {
+    const int b = blockIdx.y;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= I) return;
     const int ng = (j >> 5) * 64 + (j & 31);
-    float gsum = 0.f, usum = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float* p = partial + ((size_t)s * 16 + b) * (2 * I);
-        gsum += p[ng];
-        usum += p[ng + 32];
-    }
-    act[(size_t)b * I + j] = f2bf(gsum / (1.0f + __expf(-gsum)) * usum);
+    const float* p = partial + (size_t)b * (2 * I) + ng;
+    f32x4 gs = slab_sum4(p, (size_t)16 * 2 * I, S), us = slab_sum4(p + 32, (size_t)16 * 2 * I, S);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gs[e] / (1.0f + __expf(-gs[e])) * us[e];
+    store_frag4(act, b, j, o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // qkv partials -> (+bias) -> rope at pos = ctx_len[b] -> q_out[b][Hq*128] bf16, K/V appended to the page.
-__global__ __launch_bounds__(256) void qkv_post_decode_kernel(const float* __restrict__ partial, int S, const bf16_t* __restrict__ bias,
-                                                              const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
-                                                              const int32_t* __restrict__ block_table, int max_pages,
-                                                              bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out, int Hq, int Hkv) {
-    const int b = blockIdx.x;
+// grid (Hq + 2*Hkv, B), one wave per (sequence, head): lane owns features d = lane and d + 64 (a rope pair).
+__global__ __launch_bounds__(64) void qkv_post_decode_kernel(const float* __restrict__ partial, int S, const bf16_t* __restrict__ bias,
+                                                             const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
+                                                             const int32_t* __restrict__ block_table, int max_pages,
+                                                             bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out, int Hq, int Hkv) {
+    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const int Nq = (Hq + 2 * Hkv) * 128;
     const int pos = ctx_len[b];
     const int page = block_table[b * max_pages + (pos >> 6)];
     const int key = pos & 63;
-    auto val = [&](int n) {
-        float a = bias ? bf2f(bias[n]) : 0.f;
-        for (int s = 0; s < S; ++s) a += partial[((size_t)s * 16 + b) * Nq + n];
-        return bf2f(f2bf(a));          // the qkv projection output is a bf16 tensor
-    };
-    // rope pairs (d, d+64) of the q and k heads
-    for (int item = threadIdx.x; item < (Hq + Hkv) * 64; item += 256) {
-        const int head = item >> 6, d = item & 63;
-        const float x1 = val(head * 128 + d), x2 = val(head * 128 + d + 64);
+    const float* p = partial + (size_t)b * Nq + head * 128 + d;
+    float x1 = 0.f, x2 = 0.f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        const float a0 = p[(size_t)s * 16 * Nq], a1 = p[(size_t)(s + 1) * 16 * Nq], a2 = p[(size_t)(s + 2) * 16 * Nq], a3 = p[(size_t)(s + 3) * 16 * Nq];
+        const float b0 = p[(size_t)s * 16 * Nq + 64], b1 = p[(size_t)(s + 1) * 16 * Nq + 64], b2 = p[(size_t)(s + 2) * 16 * Nq + 64], b3 = p[(size_t)(s + 3) * 16 * Nq + 64];
+        x1 += (a0 + a1) + (a2 + a3);
+        x2 += (b0 + b1) + (b2 + b3);
+    }
+    for (; s < S; ++s) { x1 += p[(size_t)s * 16 * Nq]; x2 += p[(size_t)s * 16 * Nq + 64]; }
+    if (bias) { x1 += bf2f(bias[head * 128 + d]); x2 += bf2f(bias[head * 128 + d + 64]); }
+    x1 = bf2f(f2bf(x1)); x2 = bf2f(f2bf(x2));          // the qkv projection output is a bf16 tensor
+    if (head < Hq + Hkv) {
         float sn, cs;
         sincosf((float)pos * inv_freq[d], &sn, &cs);
         const bf16_t o1 = f2bf(x1 * cs - x2 * sn), o2 = f2bf(x2 * cs + x1 * sn);
@@ -238,11 +283,10 @@ __global__ __launch_bounds__(256) void qkv_post_decode_kernel(const float* __res
             kp[k_chunk(key, d) * 8 + (d & 7)] = o1;
             kp[k_chunk(key, d + 64) * 8 + (d & 7)] = o2;
         }
-    }
-    for (int item = threadIdx.x; item < Hkv * 128; item += 256) {
-        const int head = item >> 7, d = item & 127;
-        bf16_t* vp = pool + ((size_t)(page * Hkv + head) * 2 + 1) * PAGE_ELEMS;
-        vp[v_off(key, d)] = f2bf(val((Hq + Hkv + head) * 128 + d));
+    } else {
+        bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
+        vp[v_off(key, d)] = f2bf(x1);
+        vp[v_off(key, d + 64)] = f2bf(x2);
     }
 }
 
@@ -375,37 +419,52 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
         acc += part_o[base * 128 + d] * f;
         lsum += part_ml[base * 2 + 1] * f;
     }
-    out[((size_t)b * Hq + head) * 128 + d] = f2bf(acc / lsum);
+    out[frag_off(b, head * 128 + d)] = f2bf(acc / lsum);          // fragment-order input of the o projection
 }
 
 // ------------------------------------------------------------------------------------------------
-// greedy step glue: argmax (first index wins ties, like torch.argmax), EOS / length bookkeeping.
-__global__ __launch_bounds__(1024) void argmax_step_kernel(const float* __restrict__ logits, int V, int ld, int32_t* __restrict__ cur_tokens,
-                                                           int32_t* __restrict__ ctx_len, int32_t* __restrict__ out_ids,
-                                                           int32_t* __restrict__ out_lens, int32_t* __restrict__ finished,
-                                                           const int32_t* __restrict__ eos_ids, int n_eos, int max_new_tokens,
-                                                           int advance_ctx, const int32_t* __restrict__ forced) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    const int b = blockIdx.x;
+// greedy step glue: argmax (first index wins ties, like torch.argmax) in two stages, then EOS / length bookkeeping.
+constexpr int ARGMAX_CHUNKS = 64;
+
+DEVI void argmax_merge(float& best, int& bi, float ov, int oi) {
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+}
+
+// grid (ARGMAX_CHUNKS, B): partial (value, index) of one vocabulary chunk
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ logits, int V, int ld,
+                                                             float* __restrict__ pval, int32_t* __restrict__ pidx) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int per = (V + ARGMAX_CHUNKS - 1) / ARGMAX_CHUNKS;
+    const int lo = c * per, hi = min(V, lo + per);
     const float* row = logits + (size_t)b * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 1024) {
-        const float v = row[i];
-        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
-    }
+    for (int i = lo + threadIdx.x; i < hi; i += 256) argmax_merge(best, bi, row[i], i);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; ++k)
-            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        for (int k = 1; k < 4; ++k) argmax_merge(best, bi, sv[k], si[k]);
+        pval[b * ARGMAX_CHUNKS + c] = best;
+        pidx[b * ARGMAX_CHUNKS + c] = bi;
+    }
+}
+
+// grid B, one wave: final merge + bookkeeping
+__global__ __launch_bounds__(64) void argmax_step_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                         int32_t* __restrict__ cur_tokens, int32_t* __restrict__ ctx_len,
+                                                         int32_t* __restrict__ out_ids, int32_t* __restrict__ out_lens,
+                                                         int32_t* __restrict__ finished, const int32_t* __restrict__ eos_ids, int n_eos,
+                                                         int max_new_tokens, int advance_ctx) {
+    const int b = blockIdx.x;
+    float best = pval[b * ARGMAX_CHUNKS + threadIdx.x];
+    int bi = pidx[b * ARGMAX_CHUNKS + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    if (threadIdx.x == 0) {
         if (advance_ctx) ctx_len[b] += 1;
         if (!finished[b]) {
             const int n = out_lens[b];
@@ -415,7 +474,7 @@ __global__ __launch_bounds__(1024) void argmax_step_kernel(const float* __restri
             for (int k = 0; k < n_eos; ++k) eos = eos || (bi == eos_ids[k]);
             if (eos || n + 1 >= max_new_tokens) finished[b] = 1;
         }
-        cur_tokens[b] = (forced && forced[b] >= 0) ? forced[b] : bi;
+        cur_tokens[b] = bi;
     }
 }
 
@@ -429,9 +488,16 @@ hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv,
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* X, const bf16_t* W, float* partial, int N, int K, int splitk) {
-    if (N % 16 != 0 || K % 128 != 0 || splitk < 1 || splitk > K / 128) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 63) / 64, splitk), dim3(256), 0, s, X, W, partial, N, K, splitk);
+hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk) {
+    if (N % 16 != 0 || K % 32 != 0 || splitk < 1 || splitk > K / 32 || M < 1 || M > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 63) / 64, splitk), dim3(256), 0, s, Xf, Wd, partial, N, K, splitk, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K) {
+    if (K % 32 != 0) return hipErrorInvalidValue;
+    const int64_t chunks = (rows + 15) / 16 * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, src, dst, (int)rows, K);
     return hipGetLastError();
 }
 
@@ -442,27 +508,28 @@ hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float
 
 hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
                                 bf16_t* h, bf16_t* xn, int B, int dim, float eps) {
-    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(B), dim3(256), 0, s, tokens, embed, w, h, xn, dim, eps);
+    if (dim > ROW_THREADS * 4 || dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(B), dim3(ROW_THREADS), 0, s, tokens, embed, w, h, xn, dim, eps);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
                                           bf16_t* xn, int B, int dim, float eps) {
-    if (dim > 8 * 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(reduce_residual_rmsnorm_kernel, dim3(B), dim3(256), 0, s, partial, splitk, h, w, xn, dim, eps);
+    if (dim > ROW_THREADS * 4 || dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_residual_rmsnorm_kernel, dim3(B), dim3(ROW_THREADS), 0, s, partial, splitk, h, w, xn, dim, eps);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B) {
-    hipLaunchKernelGGL(reduce_swiglu_kernel, dim3((B * I + 255) / 256), dim3(256), 0, s, partial, splitk, act, I, B);
+    hipLaunchKernelGGL(reduce_swiglu_kernel, dim3((I / 4 + 255) / 256, B), dim3(256), 0, s, partial, splitk, act, I);
     return hipGetLastError();
 }
 
 hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
                                   const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
                                   int max_pages, bf16_t* pool_layer, bf16_t* q_out, int B, int Hq, int Hkv) {
-    hipLaunchKernelGGL(qkv_post_decode_kernel, dim3(B), dim3(256), 0, s, partial, splitk, bias, inv_freq, ctx_len, block_table,
-                       max_pages, pool_layer, q_out, Hq, Hkv);
+    hipLaunchKernelGGL(qkv_post_decode_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, s, partial, splitk, bias, inv_freq, ctx_len,
+                       block_table, max_pages, pool_layer, q_out, Hq, Hkv);
     return hipGetLastError();
 }
 
@@ -481,10 +548,11 @@ hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const 
     return hipGetLastError();
 }
 
-hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, int32_t* cur_tokens, int32_t* ctx_len,
-                              int32_t* out_ids, int32_t* out_lens, int32_t* finished, const int32_t* eos_ids, int n_eos,
-                              int max_new_tokens, int advance_ctx, const int32_t* forced) {
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(1024), 0, s, logits, V, ld, cur_tokens, ctx_len, out_ids, out_lens,
-                       finished, eos_ids, n_eos, max_new_tokens, advance_ctx, forced);
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx,
+                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
+                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx) {
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_CHUNKS, B), dim3(256), 0, s, logits, V, ld, pval, pidx);
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, cur_tokens, ctx_len, out_ids, out_lens,
+                       finished, eos_ids, n_eos, max_new_tokens, advance_ctx);
     return hipGetLastError();
 }

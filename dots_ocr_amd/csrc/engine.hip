@@ -33,7 +33,10 @@ struct Tensor {
 };
 
 struct VLayer { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *w13, *b13, *w2, *b2; };
-struct LLayer { bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *w13, *down_w; };
+struct LLayer {
+    bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *w13, *down_w;          // row-major [N][K]: prefill GEMMs
+    bf16_t *qkv_wd, *o_wd, *w13_wd, *down_wd;                        // MFMA fragment order: decode skinny GEMMs
+};
 
 __global__ void pack_w13_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up, bf16_t* __restrict__ out, int I, int K) {
     // out row r: group G = r/64; rows [0,32) of the group = gate[G*32 ..], rows [32,64) = up[G*32 ..]
@@ -98,7 +101,7 @@ struct DotsEngine {
     int patch_k = 0, patch_kpad = 0;
     std::vector<VLayer> vl;
     bf16_t *v_post_norm = nullptr, *m_ln_w = nullptr, *m_ln_b = nullptr, *m0_w = nullptr, *m0_b = nullptr, *m2_w = nullptr, *m2_b = nullptr;
-    bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
+    bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr, *lm_head_d = nullptr;
     std::vector<LLayer> ll;
     float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
 
@@ -132,7 +135,8 @@ struct DotsEngine {
     bf16_t* pool = nullptr;                // [layers][max_batch*max_pages][Hkv][2][8192]
     size_t pool_layer_elems = 0;
     int32_t *block_table = nullptr, *ctx_len = nullptr, *cur_tokens = nullptr, *out_ids = nullptr, *out_lens = nullptr,
-            *finished = nullptr, *eos_ids = nullptr, *forced = nullptr;
+            *finished = nullptr, *eos_ids = nullptr, *am_idx = nullptr;
+    float* am_val = nullptr;
     int n_eos = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
     bf16_t *d_h = nullptr, *d_xn = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
@@ -182,9 +186,10 @@ struct DotsEngine {
 namespace {
 
 int skinny_splits(int N, int K) {
+    // aim for ~1024 workgroups (4 per CU) so every CU keeps several 8-KiB-deep weight streams in flight
     const int blocks = (N + 63) / 64;
-    int s = (512 + blocks / 2) / blocks;
-    s = std::max(1, std::min(s, std::min(K / 128, 16)));
+    int s = (1024 + blocks / 2) / blocks;
+    s = std::max(1, std::min(s, std::min(K / 64, 16)));
     return s;
 }
 
@@ -282,6 +287,8 @@ int finalize_weights(DotsEngine* e) {
     RET(need(e, "model.norm.weight", {H}, &e->final_norm));
     if (find(e, "lm_head.weight")) RET(need(e, "lm_head.weight", {c.vocab_size, H}, &e->lm_head));
     else e->lm_head = e->embed;                      // tie_word_embeddings
+    CK(e->alloc(&e->lm_head_d, (size_t)c.vocab_size * H));
+    CK(launch_pack_frag(s, e->lm_head, e->lm_head_d, c.vocab_size, H));
     e->ll.resize(c.num_layers);
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
@@ -312,6 +319,15 @@ int finalize_weights(DotsEngine* e) {
         }
         CK(e->alloc(&L.w13, (size_t)2 * I * H));
         CK(launch_pack_w13(s, gw, uw, L.w13, I, H));
+        // decode copies in MFMA fragment order (+3.1 GB of 288 GB: every decode weight load is a contiguous 1 KiB)
+        CK(e->alloc(&L.qkv_wd, (size_t)(Nq + 2 * Nkv) * H));
+        CK(e->alloc(&L.o_wd, (size_t)H * Nq));
+        CK(e->alloc(&L.w13_wd, (size_t)2 * I * H));
+        CK(e->alloc(&L.down_wd, (size_t)H * I));
+        CK(launch_pack_frag(s, L.qkv_w, L.qkv_wd, Nq + 2 * Nkv, H));
+        CK(launch_pack_frag(s, L.o_w, L.o_wd, H, Nq));
+        CK(launch_pack_frag(s, L.w13, L.w13_wd, 2 * I, H));
+        CK(launch_pack_frag(s, L.down_w, L.down_wd, H, I));
         CK(hipStreamSynchronize(s));
         for (const char* n : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                               "mlp.gate_proj.weight", "mlp.up_proj.weight"})
@@ -383,8 +399,8 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->out_lens, (size_t)mb));
     CK(e->alloc(&e->finished, (size_t)mb));
     CK(e->alloc(&e->eos_ids, (size_t)16));
-    CK(e->alloc(&e->forced, (size_t)mb));
-    CK(hipMemsetAsync(e->forced, 0xff, (size_t)mb * 4, e->stream));
+    CK(e->alloc(&e->am_idx, (size_t)mb * 64));
+    CK(e->alloc(&e->am_val, (size_t)mb * 64));
     CK(e->alloc(&e->d_h, (size_t)16 * H));
     CK(e->alloc(&e->d_xn, (size_t)16 * H));
     CK(e->alloc(&e->d_q, (size_t)16 * Nq));
@@ -570,10 +586,10 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     }
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, e->d_h, B, H));
-    CK(launch_rmsnorm(s, e->d_h, e->final_norm, e->d_xn, B, H, c.rms_norm_eps));
-    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head, e->d_logits, c.vocab_size, H, 1));
-    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->cur_tokens, e->ctx_len, e->out_ids, e->out_lens,
-                          e->finished, e->eos_ids, e->n_eos, e->out_cap, 0, e->forced));
+    CK(launch_embed_rmsnorm(s, nullptr, nullptr, e->final_norm, e->d_h, e->d_xn, B, H, c.rms_norm_eps));
+    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head_d, e->d_logits, B, c.vocab_size, H, 1));
+    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
+                          e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 0));
     CK(hipEventRecord(e->ev[3], s));
     e->B = B;
     e->h_prompt_lens = L;
@@ -599,24 +615,24 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
         const LLayer& L = e->ll[i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         int S = skinny_splits(NQKV, H);
-        CK(launch_gemm_skinny(s, e->d_xn, L.qkv_w, e->d_partial, NQKV, H, S));
+        CK(launch_gemm_skinny(s, e->d_xn, L.qkv_wd, e->d_partial, B, NQKV, H, S));
         CK(launch_qkv_post_decode(s, e->d_partial, S, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, Hq, Hkv));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->d_att, B, Hq, Hkv, n_splits));
         S = skinny_splits(H, Nq);
-        CK(launch_gemm_skinny(s, e->d_att, L.o_w, e->d_partial, H, Nq, S));
+        CK(launch_gemm_skinny(s, e->d_att, L.o_wd, e->d_partial, B, H, Nq, S));
         CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, L.ln2, e->d_xn, B, H, c.rms_norm_eps));
         S = skinny_splits(2 * I, H);
-        CK(launch_gemm_skinny(s, e->d_xn, L.w13, e->d_partial, 2 * I, H, S));
+        CK(launch_gemm_skinny(s, e->d_xn, L.w13_wd, e->d_partial, B, 2 * I, H, S));
         CK(launch_reduce_swiglu(s, e->d_partial, S, e->d_act, I, B));
         S = skinny_splits(H, I);
-        CK(launch_gemm_skinny(s, e->d_act, L.down_w, e->d_partial, H, I, S));
+        CK(launch_gemm_skinny(s, e->d_act, L.down_wd, e->d_partial, B, H, I, S));
         const bf16_t* next_norm = (i + 1 < c.num_layers) ? e->ll[i + 1].ln1 : e->final_norm;
         CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, next_norm, e->d_xn, B, H, c.rms_norm_eps));
     }
-    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head, e->d_logits, c.vocab_size, H, 1));
-    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->cur_tokens, e->ctx_len, e->out_ids, e->out_lens,
-                          e->finished, e->eos_ids, e->n_eos, e->out_cap, 1, e->forced));
+    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head_d, e->d_logits, B, c.vocab_size, H, 1));
+    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
+                          e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 1));
     return DOTS_OK;
 }
 
@@ -997,11 +1013,16 @@ int dots_op_gemm_skinny(DotsEngine* e, const void* X, const void* W, void* out_f
     CK(hipSetDevice(e->device));
     const int S = skinny_splits(N, K);
     float* partial = nullptr;
+    bf16_t *xf = nullptr, *wd = nullptr;
     CK(e->alloc(&partial, (size_t)S * 16 * N));
-    hipError_t r = launch_gemm_skinny(e->stream, (const bf16_t*)X, (const bf16_t*)W, partial, N, K, S);
+    CK(e->alloc(&xf, (size_t)16 * K));
+    CK(e->alloc(&wd, (size_t)N * K));
+    hipError_t r = launch_pack_frag(e->stream, (const bf16_t*)X, xf, 16, K);
+    if (r == hipSuccess) r = launch_pack_frag(e->stream, (const bf16_t*)W, wd, N, K);
+    if (r == hipSuccess) r = launch_gemm_skinny(e->stream, xf, wd, partial, 16, N, K, S);
     if (r == hipSuccess) r = launch_skinny_reduce_plain(e->stream, partial, (float*)out_f32, N, S);
     hipStreamSynchronize(e->stream);
-    e->release(partial);
+    e->release(partial); e->release(xf); e->release(wd);
     CK(r);
     return DOTS_OK;
 }

@@ -39,7 +39,7 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
 // ---- decode.hip  (KV page pool layout documented there)
 hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
                               const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv);
-hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* X, const bf16_t* W, float* partial, int N, int K, int splitk);
+hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk);   // fragment-order operands
 hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk);
 hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
                                 bf16_t* h, bf16_t* xn, int B, int dim, float eps);
@@ -54,9 +54,11 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
                               int B, int Hq, int Hkv, int n_splits, float scale);
 hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits);
-hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, int32_t* cur_tokens, int32_t* ctx_len,
-                              int32_t* out_ids, int32_t* out_lens, int32_t* finished, const int32_t* eos_ids, int n_eos,
-                              int max_new_tokens, int advance_ctx, const int32_t* forced);
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx,
+                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
+                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx);
+// row-major [rows, K] -> MFMA fragment order (decode.hip): 16-row tiles x K/32 chunks of 1 KiB
+hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K);
 // ---- engine.hip helper kernels
 hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
 hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);
