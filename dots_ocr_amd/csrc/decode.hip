@@ -30,6 +30,8 @@ constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
 // instruction instead of 64 quarter-used sectors with row-major operands: measured 2.1 -> see profiles/).
 DEVI size_t frag_off(int m, int k) { return ((size_t)((k >> 5) * 64 + ((k >> 3) & 3) * 16 + m)) * 8 + (k & 7); }
 
+DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, float a, float b, float c, float d);
+
 DEVI int k_chunk(int key, int d) { return ((key >> 4) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (key & 15); }
 DEVI int v_off(int key, int d) {
     const int kk = key & 31;
@@ -123,6 +125,63 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     // D[n = 4g + r][m = i]  ->  partial[s][m][n0 + 4g .. +3]
     f32x4 r = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
     if (i < M) *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;     // padding rows are never stored
+}
+
+// Gate/up projection fused with SwiGLU: N = 2I is large enough (I/16 >= 256 tile pairs) that no
+// cross-block split-K is needed.  One workgroup = one (gate tile, up tile) pair of the packed W13
+// (rows [64G+16a, +16) gate and [64G+32+16a, +16) up); its 4 waves split K four ways, reduce through
+// LDS and write silu(g)*u straight into the fragment-order input of the down projection.
+__global__ __launch_bounds__(256) void gemm_skinny_swiglu_kernel(const bf16_t* __restrict__ Xf, const bf16_t* __restrict__ Wd,
+                                                                 bf16_t* __restrict__ act, int I, int K, int M) {
+    __shared__ __attribute__((aligned(16))) float red[4][2][64][4];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = l & 15, g = l >> 4;
+    const int pair = blockIdx.x;                         // 0 .. I/16
+    const int G = pair >> 1, a = pair & 1;
+    const int gate_tile = G * 4 + a, up_tile = G * 4 + 2 + a;      // 16-row tiles of the packed [2I, K] matrix
+    const int KS = K / 32;
+    const int k0 = w * KS / 4, k1 = (w + 1) * KS / 4;
+    const bf16x8* wg = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)gate_tile * KS) * 64 + l;
+    const bf16x8* wu = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)up_tile * KS) * 64 + l;
+    const bf16x8* xp = reinterpret_cast<const bf16x8*>(Xf) + l;
+    f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
+    int ks = k0;
+    for (; ks + 4 <= k1; ks += 4) {
+        bf16x8 a_[4], u_[4], b_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a_[j] = __builtin_nontemporal_load(wg + (size_t)(ks + j) * 64);
+            u_[j] = __builtin_nontemporal_load(wu + (size_t)(ks + j) * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_[j] = xp[(size_t)(ks + j) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[j], b_[j], ag, 0, 0, 0);
+            au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[j], b_[j], au, 0, 0, 0);
+        }
+    }
+    for (; ks < k1; ++ks) {
+        bf16x8 b = xp[(size_t)ks * 64];
+        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load(wg + (size_t)ks * 64), b, ag, 0, 0, 0);
+        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load(wu + (size_t)ks * 64), b, au, 0, 0, 0);
+    }
+    *reinterpret_cast<f32x4*>(&red[w][0][l][0]) = ag;
+    *reinterpret_cast<f32x4*>(&red[w][1][l][0]) = au;
+    __syncthreads();
+    if (w == 0 && i < M) {
+        f32x4 gs = ag, us = au;
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            gs += *reinterpret_cast<const f32x4*>(&red[ww][0][l][0]);
+            us += *reinterpret_cast<const f32x4*>(&red[ww][1][l][0]);
+        }
+        // lane (m = i, g): columns j = 32G + 16a + 4g + r
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
+        store_frag4(act, i, G * 32 + a * 16 + 4 * g, o[0], o[1], o[2], o[3]);
+    }
 }
 
 // row-major [rows, K] -> fragment order (weights: rows = N, 16-row tiles; inputs: one 16-row tile)
@@ -405,21 +464,38 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     }
 }
 
-// out[b][head*128 + d] = sum_s w_s O_s / sum_s w_s l_s   (grid (Hq, B), block 128)
+// out[b][head*128 + d] = sum_s w_s O_s / sum_s w_s l_s   (grid (Hq, B), block 128).
+// The split weights are computed once by the first wave (lane = split), kept in LDS; the per-feature
+// accumulation then issues its n_splits loads independently (unrolled by 4), not as a dependent chain.
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                   bf16_t* __restrict__ out, int Hq, int Hkv, int n_splits) {
+    __shared__ float wts[64];
+    __shared__ float inv_l;
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const int group = Hq / Hkv, hkv = head / group, j = head % group;
-    float m = -1e30f;
-    for (int s = 0; s < n_splits; ++s) m = fmaxf(m, part_ml[((((size_t)b * Hkv + hkv) * n_splits + s) * group + j) * 2]);
-    float acc = 0.f, lsum = 0.f;
-    for (int s = 0; s < n_splits; ++s) {
-        const size_t base = (((size_t)b * Hkv + hkv) * n_splits + s) * group + j;
-        const float f = __builtin_amdgcn_exp2f(part_ml[base * 2] - m);
-        acc += part_o[base * 128 + d] * f;
-        lsum += part_ml[base * 2 + 1] * f;
+    const size_t base0 = (((size_t)b * Hkv + hkv) * n_splits) * group + j;     // + s*group
+    if (d < 64) {
+        float m = -1e30f, l = 0.f;
+        if (d < n_splits) { m = part_ml[(base0 + (size_t)d * group) * 2]; l = part_ml[(base0 + (size_t)d * group) * 2 + 1]; }
+        const float mg = wave_max(m);
+        const float f = d < n_splits ? __builtin_amdgcn_exp2f(m - mg) : 0.f;
+        wts[d] = f;
+        const float lsum = wave_sum(l * f);
+        if (d == 0) inv_l = 1.0f / lsum;
     }
-    out[frag_off(b, head * 128 + d)] = f2bf(acc / lsum);          // fragment-order input of the o projection
+    __syncthreads();
+    const float* po = part_o + base0 * 128 + d;
+    const size_t stride = (size_t)group * 128;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= n_splits; s += 4) {
+        a0 += po[(size_t)s * stride] * wts[s];
+        a1 += po[(size_t)(s + 1) * stride] * wts[s + 1];
+        a2 += po[(size_t)(s + 2) * stride] * wts[s + 2];
+        a3 += po[(size_t)(s + 3) * stride] * wts[s + 3];
+    }
+    for (; s < n_splits; ++s) a0 += po[(size_t)s * stride] * wts[s];
+    out[frag_off(b, head * 128 + d)] = f2bf(((a0 + a1) + (a2 + a3)) * inv_l);     // fragment-order input of the o projection
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -491,6 +567,12 @@ hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv,
 hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk) {
     if (N % 16 != 0 || K % 32 != 0 || splitk < 1 || splitk > K / 32 || M < 1 || M > 16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 63) / 64, splitk), dim3(256), 0, s, Xf, Wd, partial, N, K, splitk, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_skinny_swiglu(hipStream_t s, const bf16_t* Xf, const bf16_t* W13d, bf16_t* act, int M, int I, int K) {
+    if (I % 32 != 0 || K % 32 != 0 || M < 1 || M > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_skinny_swiglu_kernel, dim3(I / 16), dim3(256), 0, s, Xf, W13d, act, I, K, M);
     return hipGetLastError();
 }
 

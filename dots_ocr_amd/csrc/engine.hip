@@ -622,9 +622,7 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
         S = skinny_splits(H, Nq);
         CK(launch_gemm_skinny(s, e->d_att, L.o_wd, e->d_partial, B, H, Nq, S));
         CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, L.ln2, e->d_xn, B, H, c.rms_norm_eps));
-        S = skinny_splits(2 * I, H);
-        CK(launch_gemm_skinny(s, e->d_xn, L.w13_wd, e->d_partial, B, 2 * I, H, S));
-        CK(launch_reduce_swiglu(s, e->d_partial, S, e->d_act, I, B));
+        CK(launch_gemm_skinny_swiglu(s, e->d_xn, L.w13_wd, e->d_act, B, I, H));
         S = skinny_splits(H, I);
         CK(launch_gemm_skinny(s, e->d_act, L.down_wd, e->d_partial, B, H, I, S));
         const bf16_t* next_norm = (i + 1 < c.num_layers) ? e->ll[i + 1].ln1 : e->final_norm;

@@ -45,6 +45,7 @@ hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16
                                 bf16_t* h, bf16_t* xn, int B, int dim, float eps);
 hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
                                           bf16_t* xn, int B, int dim, float eps);
+hipError_t launch_gemm_skinny_swiglu(hipStream_t s, const bf16_t* Xf, const bf16_t* W13d, bf16_t* act, int M, int I, int K);
 hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B);
 hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
                                   const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
