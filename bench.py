@@ -150,6 +150,12 @@ def main():
         dec_s = phase["decode_ms"] / 1e3
         dec_gbs = last["decode_bytes"] * K / dec_s / 1e9 if dec_s > 0 else 0.0
         vit_s = phase["vit_ms"] / 1e3
+        traffic = None
+        tf = ROOT / "profiles" / "r01_flash_attn_traffic.json"
+        if a.workload == "a4" and B == 8 and tf.exists():
+            # HBM-side bytes per launch of the roofline kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            # over this same command (corrected as MI355X_MICROARCH.md §HBM prescribes); see the file for the method.
+            traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
         res = {
             "metric": "pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (ViT + prefill + 1024-token greedy decode)",
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
@@ -163,7 +169,8 @@ def main():
             "phase_ms_per_step": {k: v / K for k, v in phase.items()},
             "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
                          "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_flash_attn_traffic.json)",
+                         "algorithmic_flops_per_launch": last["vit_attn_flops"] / max(1, last["vit_attn_launches"]),
                          "launches_per_step": last["vit_attn_launches"],
                          "avg_launch_ms": phase["vit_attn_ms"] / K / max(1, last["vit_attn_launches"])},
             "roofline_vit": {"bound": "mfma", "achieved": last["vit_flops"] * K / vit_s / 1e12 if vit_s > 0 else 0.0,

@@ -25,16 +25,17 @@ namespace {
 constexpr int KT_BYTES = 64 * 256;    // K tile
 constexpr int VT_BYTES = 128 * 128;   // V^T tile
 constexpr int BUF_BYTES = KT_BYTES + VT_BYTES;
+constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64; THR = 0 reproduces the textbook rescale-every-tile
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
-    bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int64_t T, int64_t Tpad, int Hq, int group,
+    bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
     float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
 
-    const QBlock qb = blocks[blockIdx.x];
-    const int h = blockIdx.y;
+    const QBlock qb = blocks[xcd_remap(blockIdx.x, n_items)];
+    const int h = qb.head;
     const int hkv = h / group;
     const int tid = threadIdx.x, l = tid & 63, l31 = l & 31, hi = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,9 +142,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * scale_log2e);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // Deferred rescale (guide T13): keep the old running max while it is exceeded by at most 2^RESCALE_THR
+        // for every row of the wave; P is then bounded by 2^RESCALE_THR instead of 1 (fp32 sum and bf16's 8-bit
+        // exponent have the headroom).  When the branch fires, O and l — everything still expressed against the
+        // old max — are scaled exactly once, before this tile's P is formed against the new max.
+        const float m_cand = mx * scale_log2e;
+        if (!__all(m_cand - m_run <= RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, m_cand);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         float psum = 0.f;
         bf16x8 pf[4];
 #pragma unroll
@@ -153,18 +166,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
                 u32x4 pk;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p0 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e], scale_log2e, -m_new));
-                    float p1 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e + 1], scale_log2e, -m_new));
+                    float p0 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e], scale_log2e, -m_run));
+                    float p1 = __builtin_amdgcn_exp2f(fmaf(s[t][8 * u + 2 * e + 1], scale_log2e, -m_run));
                     psum += p0 + p1;
                     pk[e] = pack_bf2(p0, p1);
                 }
                 pf[t * 2 + u] = __builtin_bit_cast(bf16x8, pk);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T : 4 d tiles x 4 key slabs ----
 #pragma unroll
@@ -203,10 +212,10 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
     if (n_blocks <= 0) return hipSuccess;
     if (Hq % Hkv != 0) return hipErrorInvalidValue;
     const float c = scale * 1.44269504088896340736f;
-    dim3 grid(n_blocks, Hq), block(256);
+    dim3 grid(n_blocks), block(256);         // n_blocks = work items (seq x head x query block)
     if (causal)
-        hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, s, q, k, vt, out, blocks, T, Tpad, Hq, Hq / Hkv, c);
+        hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
     else
-        hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, s, q, k, vt, out, blocks, T, Tpad, Hq, Hq / Hkv, c);
+        hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
     return hipGetLastError();
 }

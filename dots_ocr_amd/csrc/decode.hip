@@ -104,23 +104,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + l;
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(Xf) + l;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    int ks = k0;
-    for (; ks + 8 <= k1; ks += 8) {
+    // groups of up to 8 chunks; the (wave-uniform) predicates keep a ragged tail fully pipelined:
+    // all of a group's loads are in flight before its first MFMA
+    for (int ks = k0; ks < k1; ks += 8) {
         bf16x8 a[8], b[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
+        for (int j = 0; j < 8; ++j)
+            if (ks + j < k1) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = xp[(size_t)(ks + j) * 64];
+        for (int j = 0; j < 8; ++j)
+            if (ks + j < k1) b[j] = xp[(size_t)(ks + j) * 64];
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], b[j + 1], acc1, 0, 0, 0);
+            if (ks + j < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
+            if (ks + j + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], b[j + 1], acc1, 0, 0, 0);
         }
-    }
-    for (; ks < k1; ++ks) {
-        bf16x8 a = __builtin_nontemporal_load(wp + (size_t)ks * 64);
-        bf16x8 b = xp[(size_t)ks * 64];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
     }
     // D[n = 4g + r][m = i]  ->  partial[s][m][n0 + 4g .. +3]
     f32x4 r = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};

@@ -369,7 +369,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->v_cs, (size_t)e->P * 64));
     CK(e->alloc(&e->v_pos, (size_t)e->P * 2));
     CK(e->alloc(&e->v_tiles, (size_t)(e->P / 64 + 256)));
-    CK(e->alloc(&e->v_qblocks, (size_t)(e->P / 128 + 256)));
+    CK(e->alloc(&e->v_qblocks, (size_t)(e->P / 128 + 256) * c.v_heads));
 
     e->TP = c.max_prefill_tokens;
     e->TPpad = e->TP + 64 * c.max_batch;
@@ -386,7 +386,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->p_src, (size_t)e->TP));
     CK(e->alloc(&e->p_last, (size_t)16));
     CK(e->alloc(&e->p_tiles, (size_t)(e->TP / 64 + c.max_batch + 1)));
-    CK(e->alloc(&e->p_qblocks, (size_t)(e->TP / 128 + c.max_batch + 1)));
+    CK(e->alloc(&e->p_qblocks, (size_t)(e->TP / 128 + c.max_batch + 1) * c.num_heads));
 
     e->max_pages = (c.max_seq_len + 63) / 64;
     e->pool_layer_elems = (size_t)c.max_batch * e->max_pages * c.num_kv_heads * 2 * 8192;
@@ -424,14 +424,15 @@ int alloc_workspaces(DotsEngine* e) {
 }
 
 // sequences -> 64-token tiles and 128-row query blocks
-void build_worklists(const std::vector<int>& lens, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used) {
+void build_worklists(const std::vector<int>& lens, int Hq, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used) {
     tiles.clear();
     qblocks.clear();
     int tok0 = 0, pad0 = 0;
     for (size_t s = 0; s < lens.size(); ++s) {
         const int n = lens[s];
         for (int t = 0; t * 64 < n; ++t) tiles.push_back(Tile64{tok0 + t * 64, std::min(64, n - t * 64), pad0 + t * 64, (int)s, t, 0});
-        for (int q = 0; q < n; q += 128) qblocks.push_back(QBlock{q, n, tok0, pad0});
+        for (int h = 0; h < Hq; ++h)
+            for (int q = 0; q < n; q += 128) qblocks.push_back(QBlock{q, n, tok0, pad0, h, 0});
         tok0 += n;
         pad0 += (int)round_up(n, 64);
     }
@@ -479,7 +480,7 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     if (off != N) return e->fail(DOTS_E_INVALID, "grid_thw covers %lld patches, total_patches is %lld", (long long)off, (long long)N);
     if (lens.size() > 256) return e->fail(DOTS_E_CAPACITY, "more than 256 images per call");
     int64_t Tpad = 0;
-    build_worklists(lens, e->h_tiles, e->h_qblocks, &Tpad);
+    build_worklists(lens, Hh, e->h_tiles, e->h_qblocks, &Tpad);
     CK(hipMemcpyAsync(e->v_pos, e->h_pos.data(), e->h_pos.size() * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->v_tiles, e->h_tiles.data(), e->h_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->v_qblocks, e->h_qblocks.data(), e->h_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
@@ -556,7 +557,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     if (vis_used != (vis_used ? e->vis_rows : 0))
         return e->fail(DOTS_E_STATE, "prompt has %lld image tokens but the vision tower produced %lld rows", (long long)vis_used, (long long)e->vis_rows);
     int64_t Tpad = 0;
-    build_worklists(L, e->hp_tiles, e->hp_qblocks, &Tpad);
+    build_worklists(L, Hq, e->hp_tiles, e->hp_qblocks, &Tpad);
     CK(hipMemcpyAsync(e->p_pos, e->hp_pos.data(), T * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_src, e->hp_src.data(), T * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), 16 * 4, hipMemcpyHostToDevice, s));
@@ -944,11 +945,11 @@ int dots_op_gemm(DotsEngine* e, const void* A, const void* W, const void* bias, 
     return DOTS_OK;
 }
 
-static int upload_lists(DotsEngine* e, const int32_t* cu, int n_seq, std::vector<Tile64>& tiles, std::vector<QBlock>& qb,
+static int upload_lists(DotsEngine* e, const int32_t* cu, int n_seq, int Hq, std::vector<Tile64>& tiles, std::vector<QBlock>& qb,
                         Tile64** d_tiles, QBlock** d_qb, int64_t* Tpad) {
     std::vector<int> lens(n_seq);
     for (int i = 0; i < n_seq; ++i) lens[i] = cu[i + 1] - cu[i];
-    build_worklists(lens, tiles, qb, Tpad);
+    build_worklists(lens, Hq, tiles, qb, Tpad);
     CK(e->alloc(d_tiles, tiles.size() + 1));
     CK(e->alloc(d_qb, qb.size() + 1));
     CK(hipMemcpyAsync(*d_tiles, tiles.data(), tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, e->stream));
@@ -966,7 +967,7 @@ int dots_op_flash_attn(DotsEngine* e, const void* q, const void* k, const void* 
     Tile64* dt = nullptr;
     QBlock* dq = nullptr;
     int64_t Tpad = 0;
-    RET(upload_lists(e, cu, n_seq, tiles, qb, &dt, &dq, &Tpad));
+    RET(upload_lists(e, cu, n_seq, Hq, tiles, qb, &dt, &dq, &Tpad));
     const int64_t T = cu[n_seq];
     hipError_t r = launch_flash_attn(e->stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, dq, (int)qb.size(), T, Tpad, Hq, Hkv, causal, scale);
     hipStreamSynchronize(e->stream);
@@ -985,7 +986,7 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, voi
     Tile64* dt = nullptr;
     QBlock* dq = nullptr;
     int64_t Tpad = 0;
-    RET(upload_lists(e, cu, n_seq, tiles, qb, &dt, &dq, &Tpad));
+    RET(upload_lists(e, cu, n_seq, Hq, tiles, qb, &dt, &dq, &Tpad));
     const int64_t T = cu[n_seq];
     int32_t* dpos = nullptr;
     float2* cs = nullptr;

@@ -30,8 +30,9 @@ hipError_t launch_embed_gather(hipStream_t s, const int32_t* src, const bf16_t* 
 hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, bf16_t* y, int n, int dim);
 
 // ---- attn_prefill.hip
-// One work item = one 128-row query block of one sequence.
-struct QBlock { int32_t q0, n, tok0, pad0; };   // first row in seq, seq length, packed token offset, padded V^T offset
+// One work item = (sequence, head, 128-row query block); the list is ordered seq-major, then head, then block, so that
+// the XCD-contiguous remap of the 1-D grid gives one XCD (one L2) all query blocks that stream the same K/V.
+struct QBlock { int32_t q0, n, tok0, pad0, head, _pad; };   // first row in seq, seq length, packed token offset, padded V^T offset
 hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                              const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
                              int causal, float scale);
