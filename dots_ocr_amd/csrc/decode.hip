@@ -16,27 +16,10 @@
 // weights streamed straight to VGPRs in 64-B-per-lane runs (guide: "GEMV / M<=16: neither LDS nor glds"),
 // fp32 partial slabs reduced deterministically (fixed order, no atomics) inside the next fused kernel.
 #include "common.h"
+#include "decode_layout.h"
 #include "kernels.h"
 
 namespace {
-
-constexpr int PAGE = 64;
-constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
-
-// Fragment-order operand layouts of the skinny (M <= 16) GEMMs: one 1 KiB chunk per MFMA operand,
-//   weights  Wd[(n_tile*(K/32) + kstep)*64 + lane][8],  lane = g*16 + i  <->  W[16*n_tile + i][32*kstep + 8g .. +7]
-//   inputs   Xf[kstep*64 + lane][8],                     lane = g*16 + m  <->  X[m][32*kstep + 8g .. +7]
-// so every wave-level load is one contiguous, fully used 1 KiB global_load_dwordx4 (8 cache lines per
-// instruction instead of 64 quarter-used sectors with row-major operands: measured 2.1 -> see profiles/).
-DEVI size_t frag_off(int m, int k) { return ((size_t)((k >> 5) * 64 + ((k >> 3) & 3) * 16 + m)) * 8 + (k & 7); }
-
-DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, float a, float b, float c, float d);
-
-DEVI int k_chunk(int key, int d) { return ((key >> 4) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (key & 15); }
-DEVI int v_off(int key, int d) {
-    const int kk = key & 31;
-    return (((key >> 5) * 8 + (d >> 4)) * 64 + ((kk >> 2) & 3) * 16 + (d & 15)) * 8 + 4 * (kk >> 4) + (kk & 3);
-}
 
 // ------------------------------------------------------------------------------------------------
 // prefill -> pages.  grid (tiles, Hkv, 2); K from the rope'd head-major buffer, V from the qkv buffer.
@@ -125,63 +108,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     if (i < M) *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;     // padding rows are never stored
 }
 
-// Gate/up projection fused with SwiGLU: N = 2I is large enough (I/16 >= 256 tile pairs) that no
-// cross-block split-K is needed.  One workgroup = one (gate tile, up tile) pair of the packed W13
-// (rows [64G+16a, +16) gate and [64G+32+16a, +16) up); its 4 waves split K four ways, reduce through
-// LDS and write silu(g)*u straight into the fragment-order input of the down projection.
-__global__ __launch_bounds__(256) void gemm_skinny_swiglu_kernel(const bf16_t* __restrict__ Xf, const bf16_t* __restrict__ Wd,
-                                                                 bf16_t* __restrict__ act, int I, int K, int M) {
-    __shared__ __attribute__((aligned(16))) float red[4][2][64][4];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = l & 15, g = l >> 4;
-    const int pair = blockIdx.x;                         // 0 .. I/16
-    const int G = pair >> 1, a = pair & 1;
-    const int gate_tile = G * 4 + a, up_tile = G * 4 + 2 + a;      // 16-row tiles of the packed [2I, K] matrix
-    const int KS = K / 32;
-    const int k0 = w * KS / 4, k1 = (w + 1) * KS / 4;
-    const bf16x8* wg = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)gate_tile * KS) * 64 + l;
-    const bf16x8* wu = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)up_tile * KS) * 64 + l;
-    const bf16x8* xp = reinterpret_cast<const bf16x8*>(Xf) + l;
-    f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
-    int ks = k0;
-    for (; ks + 4 <= k1; ks += 4) {
-        bf16x8 a_[4], u_[4], b_[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a_[j] = __builtin_nontemporal_load(wg + (size_t)(ks + j) * 64);
-            u_[j] = __builtin_nontemporal_load(wu + (size_t)(ks + j) * 64);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b_[j] = xp[(size_t)(ks + j) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[j], b_[j], ag, 0, 0, 0);
-            au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[j], b_[j], au, 0, 0, 0);
-        }
-    }
-    for (; ks < k1; ++ks) {
-        bf16x8 b = xp[(size_t)ks * 64];
-        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load(wg + (size_t)ks * 64), b, ag, 0, 0, 0);
-        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_nontemporal_load(wu + (size_t)ks * 64), b, au, 0, 0, 0);
-    }
-    *reinterpret_cast<f32x4*>(&red[w][0][l][0]) = ag;
-    *reinterpret_cast<f32x4*>(&red[w][1][l][0]) = au;
-    __syncthreads();
-    if (w == 0 && i < M) {
-        f32x4 gs = ag, us = au;
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-            gs += *reinterpret_cast<const f32x4*>(&red[ww][0][l][0]);
-            us += *reinterpret_cast<const f32x4*>(&red[ww][1][l][0]);
-        }
-        // lane (m = i, g): columns j = 32G + 16a + 4g + r
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
-        store_frag4(act, i, G * 32 + a * 16 + 4 * g, o[0], o[1], o[2], o[3]);
-    }
-}
-
 // row-major [rows, K] -> fragment order (weights: rows = N, 16-row tiles; inputs: one 16-row tile)
 __global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;          // destination 16-B chunk
@@ -205,146 +131,6 @@ __global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* _
     float a = 0.f;
     for (int s = 0; s < S; ++s) a += partial[(size_t)s * 16 * N + idx];
     out[idx] = a;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Row kernels of the decode step.  One block per sequence row where a full-row statistic is needed
-// (rmsnorm); each thread owns 4 consecutive features so every partial-slab read is one 16-B load and
-// the S slab reads of a thread are independent (unrolled), not a dependent chain.
-constexpr int ROW_THREADS = 512;           // 512 x 4 features covers hidden <= 2048
-
-DEVI float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < ROW_THREADS / 64; ++i) t += red[i];
-    __syncthreads();
-    return t;
-}
-
-DEVI f32x4 slab_sum4(const float* __restrict__ p, size_t stride, int S) {
-    f32x4 a = {0, 0, 0, 0};
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * stride);
-        f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * stride);
-        f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * stride);
-        a += (v0 + v1) + (v2 + v3);
-    }
-    for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (size_t)s * stride);
-    return a;
-}
-
-// 4 normalised features (m, k..k+3) -> fragment-order input buffer (8-byte store)
-DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, float a, float b, float c, float d) {
-    u32x2 pk = {pack_bf2(a, b), pack_bf2(c, d)};
-    *reinterpret_cast<u32x2*>(xf + frag_off(m, k)) = pk;
-}
-
-// h[b] = rows[b] (embedding row of tokens[b], or h_in[b] when tokens == nullptr);  xn = rmsnorm(h) * w (fragment order)
-__global__ __launch_bounds__(ROW_THREADS) void embed_rmsnorm_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ embed,
-                                                                    const bf16_t* __restrict__ w, bf16_t* __restrict__ h,
-                                                                    bf16_t* __restrict__ xn, int dim, float eps) {
-    __shared__ float red[ROW_THREADS / 64];
-    const int b = blockIdx.x, k = threadIdx.x * 4;
-    const bool on = k < dim;
-    float v[4] = {0, 0, 0, 0};
-    if (on) {
-        const bf16_t* src = tokens ? embed + (size_t)tokens[b] * dim : h + (size_t)b * dim;
-        u32x2 x = *reinterpret_cast<const u32x2*>(src + k);
-        v[0] = lo_bf(x[0]); v[1] = hi_bf(x[0]); v[2] = lo_bf(x[1]); v[3] = hi_bf(x[1]);
-        if (tokens) *reinterpret_cast<u32x2*>(h + (size_t)b * dim + k) = x;
-    }
-    const float rstd = rsqrtf(block_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3], red) / dim + eps);
-    if (on) {
-        u32x2 ww = *reinterpret_cast<const u32x2*>(w + k);
-        store_frag4(xn, b, k, bf2f(f2bf(v[0] * rstd)) * lo_bf(ww[0]), bf2f(f2bf(v[1] * rstd)) * hi_bf(ww[0]),
-                    bf2f(f2bf(v[2] * rstd)) * lo_bf(ww[1]), bf2f(f2bf(v[3] * rstd)) * hi_bf(ww[1]));
-    }
-}
-
-// h[b] = bf16(h[b] + sum_s partial[s][b][:]);  xn[b] = rmsnorm(h[b]) * w (fragment order)
-__global__ __launch_bounds__(ROW_THREADS) void reduce_residual_rmsnorm_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ h,
-                                                                              const bf16_t* __restrict__ w, bf16_t* __restrict__ xn,
-                                                                              int dim, float eps) {
-    __shared__ float red[ROW_THREADS / 64];
-    const int b = blockIdx.x, k = threadIdx.x * 4;
-    const bool on = k < dim;
-    float v[4] = {0, 0, 0, 0};
-    if (on) {
-        f32x4 a = slab_sum4(partial + (size_t)b * dim + k, (size_t)16 * dim, S);
-        u32x2 x = *reinterpret_cast<const u32x2*>(h + (size_t)b * dim + k);
-        u32x2 o = {pack_bf2(lo_bf(x[0]) + a[0], hi_bf(x[0]) + a[1]), pack_bf2(lo_bf(x[1]) + a[2], hi_bf(x[1]) + a[3])};
-        *reinterpret_cast<u32x2*>(h + (size_t)b * dim + k) = o;
-        v[0] = lo_bf(o[0]); v[1] = hi_bf(o[0]); v[2] = lo_bf(o[1]); v[3] = hi_bf(o[1]);
-    }
-    const float rstd = rsqrtf(block_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3], red) / dim + eps);
-    if (on) {
-        u32x2 ww = *reinterpret_cast<const u32x2*>(w + k);
-        store_frag4(xn, b, k, bf2f(f2bf(v[0] * rstd)) * lo_bf(ww[0]), bf2f(f2bf(v[1] * rstd)) * hi_bf(ww[0]),
-                    bf2f(f2bf(v[2] * rstd)) * lo_bf(ww[1]), bf2f(f2bf(v[3] * rstd)) * hi_bf(ww[1]));
-    }
-}
-
-// act[b][j..j+3] = silu(sum_s P[s][b][gate(j)]) * sum_s P[s][b][up(j)], packed rows: group of 64 = 32 gate | 32 up.
-// grid (ceil(I/4/256), B); output in fragment order (K = I) for the down projection.
-__global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial, int S, bf16_t* __restrict__ act, int I) {
-    const int b = blockIdx.y;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j >= I) return;
-    const int ng = (j >> 5) * 64 + (j & 31);
-    const float* p = partial + (size_t)b * (2 * I) + ng;
-    f32x4 gs = slab_sum4(p, (size_t)16 * 2 * I, S), us = slab_sum4(p + 32, (size_t)16 * 2 * I, S);
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = gs[e] / (1.0f + __expf(-gs[e])) * us[e];
-    store_frag4(act, b, j, o[0], o[1], o[2], o[3]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// qkv partials -> (+bias) -> rope at pos = ctx_len[b] -> q_out[b][Hq*128] bf16, K/V appended to the page.
-// grid (Hq + 2*Hkv, B), one wave per (sequence, head): lane owns features d = lane and d + 64 (a rope pair).
-__global__ __launch_bounds__(64) void qkv_post_decode_kernel(const float* __restrict__ partial, int S, const bf16_t* __restrict__ bias,
-                                                             const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
-                                                             const int32_t* __restrict__ block_table, int max_pages,
-                                                             bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out, int Hq, int Hkv) {
-    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const int Nq = (Hq + 2 * Hkv) * 128;
-    const int pos = ctx_len[b];
-    const int page = block_table[b * max_pages + (pos >> 6)];
-    const int key = pos & 63;
-    const float* p = partial + (size_t)b * Nq + head * 128 + d;
-    float x1 = 0.f, x2 = 0.f;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        const float a0 = p[(size_t)s * 16 * Nq], a1 = p[(size_t)(s + 1) * 16 * Nq], a2 = p[(size_t)(s + 2) * 16 * Nq], a3 = p[(size_t)(s + 3) * 16 * Nq];
-        const float b0 = p[(size_t)s * 16 * Nq + 64], b1 = p[(size_t)(s + 1) * 16 * Nq + 64], b2 = p[(size_t)(s + 2) * 16 * Nq + 64], b3 = p[(size_t)(s + 3) * 16 * Nq + 64];
-        x1 += (a0 + a1) + (a2 + a3);
-        x2 += (b0 + b1) + (b2 + b3);
-    }
-    for (; s < S; ++s) { x1 += p[(size_t)s * 16 * Nq]; x2 += p[(size_t)s * 16 * Nq + 64]; }
-    if (bias) { x1 += bf2f(bias[head * 128 + d]); x2 += bf2f(bias[head * 128 + d + 64]); }
-    x1 = bf2f(f2bf(x1)); x2 = bf2f(f2bf(x2));          // the qkv projection output is a bf16 tensor
-    if (head < Hq + Hkv) {
-        float sn, cs;
-        sincosf((float)pos * inv_freq[d], &sn, &cs);
-        const bf16_t o1 = f2bf(x1 * cs - x2 * sn), o2 = f2bf(x2 * cs + x1 * sn);
-        if (head < Hq) {
-            q_out[(size_t)b * Hq * 128 + head * 128 + d] = o1;
-            q_out[(size_t)b * Hq * 128 + head * 128 + d + 64] = o2;
-        } else {
-            bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
-            kp[k_chunk(key, d) * 8 + (d & 7)] = o1;
-            kp[k_chunk(key, d + 64) * 8 + (d & 7)] = o2;
-        }
-    } else {
-        bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
-        vp[v_off(key, d)] = f2bf(x1);
-        vp[v_off(key, d + 64)] = f2bf(x2);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,12 +354,6 @@ hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd,
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_skinny_swiglu(hipStream_t s, const bf16_t* Xf, const bf16_t* W13d, bf16_t* act, int M, int I, int K) {
-    if (I % 32 != 0 || K % 32 != 0 || M < 1 || M > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_skinny_swiglu_kernel, dim3(I / 16), dim3(256), 0, s, Xf, W13d, act, I, K, M);
-    return hipGetLastError();
-}
-
 hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K) {
     if (K % 32 != 0) return hipErrorInvalidValue;
     const int64_t chunks = (rows + 15) / 16 * (K / 32) * 64;
@@ -583,33 +363,6 @@ hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64
 
 hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk) {
     hipLaunchKernelGGL(skinny_reduce_plain_kernel, dim3((16 * N + 255) / 256), dim3(256), 0, s, partial, out, N, splitk);
-    return hipGetLastError();
-}
-
-hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
-                                bf16_t* h, bf16_t* xn, int B, int dim, float eps) {
-    if (dim > ROW_THREADS * 4 || dim % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_rmsnorm_kernel, dim3(B), dim3(ROW_THREADS), 0, s, tokens, embed, w, h, xn, dim, eps);
-    return hipGetLastError();
-}
-
-hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
-                                          bf16_t* xn, int B, int dim, float eps) {
-    if (dim > ROW_THREADS * 4 || dim % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(reduce_residual_rmsnorm_kernel, dim3(B), dim3(ROW_THREADS), 0, s, partial, splitk, h, w, xn, dim, eps);
-    return hipGetLastError();
-}
-
-hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B) {
-    hipLaunchKernelGGL(reduce_swiglu_kernel, dim3((I / 4 + 255) / 256, B), dim3(256), 0, s, partial, splitk, act, I);
-    return hipGetLastError();
-}
-
-hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
-                                  const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
-                                  int max_pages, bf16_t* pool_layer, bf16_t* q_out, int B, int Hq, int Hkv) {
-    hipLaunchKernelGGL(qkv_post_decode_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, s, partial, splitk, bias, inv_freq, ctx_len,
-                       block_table, max_pages, pool_layer, q_out, Hq, Hkv);
     return hipGetLastError();
 }
 

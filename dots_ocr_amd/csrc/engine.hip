@@ -139,8 +139,8 @@ struct DotsEngine {
     float* am_val = nullptr;
     int n_eos = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
-    bf16_t *d_h = nullptr, *d_xn = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
-    float *d_partial = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
+    bf16_t *d_h = nullptr, *d_h2 = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
+    float *d_slabs = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     int B = 0;                             // sequences of the current batch
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
@@ -402,17 +402,14 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->am_idx, (size_t)mb * 64));
     CK(e->alloc(&e->am_val, (size_t)mb * 64));
     CK(e->alloc(&e->d_h, (size_t)16 * H));
-    CK(e->alloc(&e->d_xn, (size_t)16 * H));
+    CK(e->alloc(&e->d_h2, (size_t)16 * H));
+    CK(e->alloc(&e->d_slabs, (size_t)4 * 16 * H));
     CK(e->alloc(&e->d_q, (size_t)16 * Nq));
     CK(e->alloc(&e->d_att, (size_t)16 * Nq));
     CK(e->alloc(&e->d_act, (size_t)16 * c.intermediate_size));
-    size_t pmax = 0;
-    auto upd = [&](int N, int K) { pmax = std::max(pmax, (size_t)skinny_splits(N, K) * 16 * N); };
-    upd(Nq + 2 * Nkv, H); upd(H, Nq); upd(2 * c.intermediate_size, H); upd(H, c.intermediate_size); upd(c.vocab_size, H);
-    CK(e->alloc(&e->d_partial, pmax));
+    CK(e->alloc(&e->d_logits, (size_t)16 * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)16 * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)16 * c.num_heads * 64 * 2));
-    e->d_logits = e->d_partial;                  // lm_head runs with one split: its slab [16][V] IS the logits
     // identity paging: sequence slot b owns pages [b*max_pages, (b+1)*max_pages)
     e->hp_table.resize((size_t)mb * e->max_pages);
     for (int b = 0; b < mb; ++b)
@@ -587,8 +584,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     }
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, e->d_h, B, H));
-    CK(launch_embed_rmsnorm(s, nullptr, nullptr, e->final_norm, e->d_h, e->d_xn, B, H, c.rms_norm_eps));
-    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head_d, e->d_logits, B, c.vocab_size, H, 1));
+    CK(launch_dec_lmhead(s, e->d_h, nullptr, 0, nullptr, e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
                           e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 0));
     CK(hipEventRecord(e->ev[3], s));
@@ -608,28 +604,30 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
 int decode_step_launches(DotsEngine* e, int n_splits) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
-    const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, NQKV = Nq + 2 * Hkv * 128, I = c.intermediate_size;
+    const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, I = c.intermediate_size;
     const int B = e->B;
     const float scale = 1.0f / sqrtf(128.0f);
-    CK(launch_embed_rmsnorm(s, e->cur_tokens, e->embed, e->ll[0].ln1, e->d_h, e->d_xn, B, H, c.rms_norm_eps));
+    // residual stream ping-pong: a K-split down projection leaves "h + slabs" to its consumer's prologue, which
+    // materialises the new row in the other buffer (workgroup 0) while every workgroup reads the old one
+    bf16_t* hb[2] = {e->d_h, e->d_h2};
+    int cur = 0, n_slabs = 0;
+    const int down_split = (I / 32 >= 32) ? 2 : 1;      // 192 workgroups for the 27.5 MB down projection
+    CK(launch_dec_embed(s, e->cur_tokens, e->embed, hb[cur], B, H));
+    static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
     for (int i = 0; i < c.num_layers; ++i) {
-        const LLayer& L = e->ll[i];
+        const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
-        int S = skinny_splits(NQKV, H);
-        CK(launch_gemm_skinny(s, e->d_xn, L.qkv_wd, e->d_partial, B, NQKV, H, S));
-        CK(launch_qkv_post_decode(s, e->d_partial, S, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, Hq, Hkv));
+        CK(launch_dec_qkv(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], L.ln1, L.qkv_wd, L.qkv_b, e->lm_inv_freq, e->ctx_len,
+                          e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq, Hkv, c.rms_norm_eps));
+        if (n_slabs) cur ^= 1;
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->d_att, B, Hq, Hkv, n_splits));
-        S = skinny_splits(H, Nq);
-        CK(launch_gemm_skinny(s, e->d_att, L.o_wd, e->d_partial, B, H, Nq, S));
-        CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, L.ln2, e->d_xn, B, H, c.rms_norm_eps));
-        CK(launch_gemm_skinny_swiglu(s, e->d_xn, L.w13_wd, e->d_act, B, I, H));
-        S = skinny_splits(H, I);
-        CK(launch_gemm_skinny(s, e->d_act, L.down_wd, e->d_partial, B, H, I, S));
-        const bf16_t* next_norm = (i + 1 < c.num_layers) ? e->ll[i + 1].ln1 : e->final_norm;
-        CK(launch_reduce_residual_rmsnorm(s, e->d_partial, S, e->d_h, next_norm, e->d_xn, B, H, c.rms_norm_eps));
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, hb[cur], nullptr, 1, B, H, Nq));
+        CK(launch_dec_gateup(s, hb[cur], L.ln2, L.w13_wd, e->d_act, B, H, I, c.rms_norm_eps));
+        CK(launch_dec_proj(s, e->d_act, L.down_wd, hb[cur], e->d_slabs, down_split, B, H, I));
+        n_slabs = down_split > 1 ? down_split : 0;
     }
-    CK(launch_gemm_skinny(s, e->d_xn, e->lm_head_d, e->d_logits, B, c.vocab_size, H, 1));
+    CK(launch_dec_lmhead(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
                           e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 1));
     return DOTS_OK;
@@ -664,7 +662,8 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
     if (c.num_heads % c.num_kv_heads || c.num_heads / c.num_kv_heads > 16) return bad("unsupported GQA group");
     if (c.hidden_size % 128 || c.v_embed_dim % 128 || c.vocab_size % 128) return bad("hidden sizes and vocab must be multiples of 128");
     if (c.intermediate_size % 64 || c.v_intermediate % 64) return bad("intermediate sizes must be multiples of 64");
-    if (c.hidden_size > 2048) return bad("hidden_size > 2048 not supported by the decode kernels");
+    if (c.hidden_size > 2048 || c.hidden_size % 256) return bad("hidden_size must be a multiple of 256 and <= 2048 (decode kernels)");
+    if (c.num_heads * 128 < 512 || c.intermediate_size < 512) return bad("projection K too small for the 16-way in-workgroup split");
     if (c.max_batch < 1 || c.max_batch > 16) return bad("max_batch must be in [1,16]");
     if (c.max_seq_len < 64 || c.max_patches < 4 || c.max_prefill_tokens < 1) return bad("capacity fields too small");
     if (c.v_merge < 1 || c.v_temporal_patch != 1) return bad("unsupported vision patching");

@@ -42,15 +42,18 @@ hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv,
                               const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv);
 hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk);   // fragment-order operands
 hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk);
-hipError_t launch_embed_rmsnorm(hipStream_t s, const int32_t* tokens, const bf16_t* embed, const bf16_t* w,
-                                bf16_t* h, bf16_t* xn, int B, int dim, float eps);
-hipError_t launch_reduce_residual_rmsnorm(hipStream_t s, const float* partial, int splitk, bf16_t* h, const bf16_t* w,
-                                          bf16_t* xn, int B, int dim, float eps);
-hipError_t launch_gemm_skinny_swiglu(hipStream_t s, const bf16_t* Xf, const bf16_t* W13d, bf16_t* act, int M, int I, int K);
-hipError_t launch_reduce_swiglu(hipStream_t s, const float* partial, int splitk, bf16_t* act, int I, int B);
-hipError_t launch_qkv_post_decode(hipStream_t s, const float* partial, int splitk, const bf16_t* bias,
-                                  const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table,
-                                  int max_pages, bf16_t* pool_layer, bf16_t* q_out, int B, int Hq, int Hkv);
+// ---- decode_fused.hip: dense layers of the decode step with in-workgroup split-K and fused prologues/epilogues
+hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* embed, bf16_t* h, int B, int dim);
+hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
+                          const bf16_t* Wd, const bf16_t* bias,
+                          const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps);
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, bf16_t* h, float* slabs, int ksplit, int B, int N, int K);
+hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* W13d, bf16_t* act,
+                             int B, int H, int I, float eps);
+hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
+                             const bf16_t* Wd, float* logits,
+                             int B, int H, int V, float eps);
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
                               int B, int Hq, int Hkv, int n_splits, float scale);

@@ -168,3 +168,24 @@ def test_capacity_and_state_errors(setup):
     ids = np.full(8, cfg.image_token_id, np.int32)
     with pytest.raises(DotsEngineError):
         eng.prefill(ids, np.array([8], np.int32))                                # image tokens without vision rows
+
+
+def test_batch_of_more_than_8_rows_uses_full_mfma_columns():
+    """B > 8 switches the decode kernels to the 16-row X image; results must equal the per-sequence runs."""
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=21)
+    eng = Engine(cfg, max_batch=12, max_seq_len=256, max_patches=2048, max_prefill_tokens=2048)
+    eng.load_state_dict(sd)
+    grids = [(1, 4, 4)] * 5 + [(1, 2, 6)] * 5
+    pv, grid, seqs = _inputs(cfg, grids, 5, seed=9)
+    ids = torch.cat(seqs).numpy().astype(np.int32)
+    lens = np.array([len(s) for s in seqs], np.int32)
+    out, out_lens = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=10)
+    assert out_lens.tolist() == [10] * 10
+    off = np.concatenate([[0], np.cumsum([g[1] * g[2] for g in grids])])
+    for b in (0, 4, 9):
+        single, _ = eng.generate(seqs[b].numpy().astype(np.int32), lens[b:b + 1], pv[off[b]:off[b + 1]].numpy(), grid[b:b + 1].numpy(),
+                                 max_new_tokens=10)
+        assert np.array_equal(single[0], out[b]), b
+    eng.close()
