@@ -74,9 +74,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the dots.ocr HIP engine has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (any world size)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from dots_ocr_amd import dp
@@ -112,7 +114,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
@@ -134,8 +136,8 @@ def main():
     eng.synchronize(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     # the only data-path collective: gather the generated token ids on rank 0
-    gathered = dp.gather_token_ids(out, out_lens)
-    if world > 1:
+    gathered = dp.gather_token_ids(out, out_lens, page_index=[rank * B + i for i in range(B)])
+    if use_dist:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -157,7 +159,7 @@ def main():
             # over this same command (corrected as MI355X_MICROARCH.md §HBM prescribes); see the file for the method.
             traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
         res = {
-            "metric": "pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (ViT + prefill + 1024-token greedy decode)",
+            "metric": f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (ViT + prefill + {a.max_new_tokens}-token greedy decode)",
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic pages (PIL text lines), seeded random weights at the checkpoint's dimensions",
@@ -185,7 +187,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg, sd, cores)
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

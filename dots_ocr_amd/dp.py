@@ -46,7 +46,7 @@ def gather_token_ids(out_ids: np.ndarray, out_lens: np.ndarray, page_index: Sequ
     local_idx = list(page_index) if page_index is not None else None
     try:
         import torch.distributed as dist
-        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        active = dist.is_available() and dist.is_initialized()
     except Exception:
         active = False
     if not active:
