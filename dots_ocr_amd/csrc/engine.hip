@@ -145,6 +145,11 @@ struct DotsEngine {
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
 
+    // ---- image preprocessing scratch (grown on demand)
+    uint8_t *pp_in = nullptr, *pp_tmp = nullptr, *pp_out = nullptr;
+    int32_t* pp_tab = nullptr;
+    size_t pp_in_cap = 0, pp_tmp_cap = 0, pp_out_cap = 0, pp_tab_cap = 0;
+
     // ---- timing
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> attn_ev;
@@ -853,6 +858,59 @@ int dots_get_stats(DotsEngine* e, DotsStats* out) {
     e->stats.vit_attn_ms = a;
     e->stats.vit_attn_launches = e->attn_pairs;
     *out = e->stats;
+    return DOTS_OK;
+}
+
+int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int on_device, int h, int w, int rh, int rw,
+                          const int32_t* hcoef, const int32_t* hbounds, int hk, const int32_t* vcoef, const int32_t* vbounds, int vk,
+                          const float* mean3, const float* std3, float rescale, float* out) {
+    if (!e) return DOTS_E_INVALID;
+    const DotsConfig& c = e->cfg;
+    const int P = c.v_patch, m = c.v_merge;
+    if (!rgb || !out || !mean3 || !std3 || h < 1 || w < 1 || rh < 1 || rw < 1) return e->fail(DOTS_E_INVALID, "bad preprocess arguments");
+    if (rh % (P * m) || rw % (P * m)) return e->fail(DOTS_E_INVALID, "resized size %dx%d is not a multiple of patch*merge", rh, rw);
+    if ((rw != w && (!hcoef || !hbounds || hk < 1)) || (rh != h && (!vcoef || !vbounds || vk < 1)))
+        return e->fail(DOTS_E_INVALID, "missing resample table for a resized axis");
+    if (c.v_channels != 3) return e->fail(DOTS_E_INVALID, "only 3-channel images are supported");
+    CK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    auto grow = [&](uint8_t** p, size_t* cap, size_t need) -> hipError_t {
+        if (need <= *cap) return hipSuccess;
+        if (*p) { hipStreamSynchronize(s); e->release(*p); *p = nullptr; }
+        *cap = need + need / 4;
+        return e->alloc(p, *cap);
+    };
+    const size_t in_bytes = (size_t)h * w * 3, tmp_bytes = (size_t)h * rw * 3, out_bytes = (size_t)rh * rw * 3;
+    const uint8_t* src = rgb;
+    if (!on_device) {
+        CK(grow(&e->pp_in, &e->pp_in_cap, in_bytes));
+        CK(hipMemcpyAsync(e->pp_in, rgb, in_bytes, hipMemcpyHostToDevice, s));
+        src = e->pp_in;
+    }
+    const size_t tab_ints = (rw != w ? (size_t)rw * (hk + 2) : 0) + (rh != h ? (size_t)rh * (vk + 2) : 0);
+    if (tab_ints > e->pp_tab_cap) {
+        if (e->pp_tab) { hipStreamSynchronize(s); e->release(e->pp_tab); e->pp_tab = nullptr; }
+        e->pp_tab_cap = tab_ints + tab_ints / 4;
+        CK(e->alloc(&e->pp_tab, e->pp_tab_cap));
+    }
+    int32_t* tab = e->pp_tab;
+    if (rw != w) {
+        CK(grow(&e->pp_tmp, &e->pp_tmp_cap, tmp_bytes));
+        CK(hipMemcpyAsync(tab, hcoef, (size_t)rw * hk * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(tab + (size_t)rw * hk, hbounds, (size_t)rw * 2 * 4, hipMemcpyHostToDevice, s));
+        CK(launch_resize_h(s, src, e->pp_tmp, tab, tab + (size_t)rw * hk, hk, h, w, rw));
+        src = e->pp_tmp;
+        tab += (size_t)rw * (hk + 2);
+    }
+    if (rh != h) {
+        CK(grow(&e->pp_out, &e->pp_out_cap, out_bytes));
+        CK(hipMemcpyAsync(tab, vcoef, (size_t)rh * vk * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(tab + (size_t)rh * vk, vbounds, (size_t)rh * 2 * 4, hipMemcpyHostToDevice, s));
+        CK(launch_resize_v(s, src, e->pp_out, tab, tab + (size_t)rh * vk, vk, rw, rh));
+        src = e->pp_out;
+    }
+    CK(launch_normalize_patchify(s, src, out, rw, rh / P, rw / P, P, m, rescale, mean3, std3));
+    CK(hipStreamSynchronize(s));          // the host tables / image buffers may be reused by the caller
     return DOTS_OK;
 }
 

@@ -67,3 +67,11 @@ hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64
 // ---- engine.hip helper kernels
 hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
 hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);
+
+// ---- preprocess.hip: Pillow-exact bicubic resize + normalise + patchify on the GPU
+hipError_t launch_resize_h(hipStream_t s, const uint8_t* in, uint8_t* out, const int32_t* coef, const int32_t* bounds,
+                           int ksize, int H, int W, int rw);
+hipError_t launch_resize_v(hipStream_t s, const uint8_t* in, uint8_t* out, const int32_t* coef, const int32_t* bounds,
+                           int ksize, int W, int rh);
+hipError_t launch_normalize_patchify(hipStream_t s, const uint8_t* img, float* out, int rw, int gh, int gw, int P, int m,
+                                     float r255, const float* mean, const float* stdv);

@@ -67,6 +67,7 @@ def _prototypes(lib):
         "dots_prefill": (i32, [vp, P(i32), P(i32), i32]),
         "dots_decode_step": (i32, [vp]),
         "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
+        "dots_preprocess_image": (i32, [vp, vp, i32, i32, i32, i32, i32, P(i32), P(i32), i32, P(i32), P(i32), i32, P(f32), P(f32), f32, vp]),
         "dots_get_logits": (i32, [vp, P(f32)]),
         "dots_set_next_tokens": (i32, [vp, P(i32), i32]),
         "dots_get_last_tokens": (i32, [vp, P(i32)]),
@@ -93,7 +94,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_prefill", "dots_decode_step", "dots_generate", "dots_get_logits",
+    "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_get_logits",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma",
@@ -214,6 +215,32 @@ class Engine:
         self._ck(self.lib.dots_vit_forward(self.h, ptr, int(on_device), n, _i64p(grid), grid.shape[0],
                                            C.c_void_p(out_dev) if out_dev else None), "dots_vit_forward")
         return n // (self.cfg.vision.spatial_merge_size ** 2)
+
+    def preprocess_image(self, rgb: np.ndarray, out_dev: int, min_pixels: Optional[int] = None, max_pixels: Optional[int] = None):
+        """uint8 [h, w, 3] host image -> float32 patches written at device pointer `out_dev`; returns [t, gh, gw].
+        Bit-identical to image_utils.preprocess_image (Pillow BICUBIC + normalise + patchify), computed on the GPU."""
+        from .image_utils import bicubic_resample_tables, smart_resize
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, _ = rgb.shape
+        v = self.cfg.vision
+        rh, rw = smart_resize(h, w, v.patch_size * v.spatial_merge_size, min_pixels or self.cfg.min_pixels, max_pixels or self.cfg.max_pixels)
+        hc = hb = vc = vb = None
+        hk = vk = 0
+        if rw != w:
+            hc, hb = bicubic_resample_tables(w, rw)
+            hk = hc.shape[1]
+        if rh != h:
+            vc, vb = bicubic_resample_tables(h, rh)
+            vk = vc.shape[1]
+        mean = np.asarray(self.cfg.image_mean, np.float32)
+        std = np.asarray(self.cfg.image_std, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self._ck(self.lib.dots_preprocess_image(
+            self.h, rgb.ctypes.data_as(C.c_void_p), 0, h, w, rh, rw,
+            _i32p(hc) if hc is not None else None, _i32p(hb) if hb is not None else None, hk,
+            _i32p(vc) if vc is not None else None, _i32p(vb) if vb is not None else None, vk,
+            fp(mean), fp(std), float(np.float32(1.0 / 255.0)), C.c_void_p(out_dev)), "dots_preprocess_image")
+        return [1, rh // v.patch_size, rw // v.patch_size]
 
     def prefill(self, input_ids: np.ndarray, prompt_lens: np.ndarray):
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)

@@ -141,3 +141,34 @@ def preprocess_image(image: Image.Image, patch_size: int = 14, merge_size: int =
         tiles = np.repeat(tiles[:, :, :, :, :, None], temporal_patch_size, axis=5)
     flat = np.ascontiguousarray(tiles.reshape(gh * gw, c * temporal_patch_size * patch_size * patch_size), dtype=np.float32)
     return flat, [1, gh, gw]
+
+
+# ------------------------------------------------------------------------------ device preprocessing (host half)
+def bicubic_resample_tables(in_size: int, out_size: int):
+    """Fixed-point tap tables of Pillow's BICUBIC resampler for one axis (vectorised): int32 coeffs [out, ksize] and
+    int32 bounds [out, 2] = (first input index, tap count).  The GPU kernels (csrc/preprocess.hip) apply them with
+    Pillow's exact integer arithmetic (22 fractional bits, round, clip to uint8 after each pass), so the device path
+    is bit-identical to `Image.resize(..., BICUBIC)` used by `preprocess_image`."""
+    bits = 22
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # C (int) cast truncates; values are >= -support > INT_MIN
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    taps = np.arange(ksize, dtype=np.float64)[None, :]
+    x = np.abs((taps + xmin[:, None] - center[:, None] + 0.5) * (1.0 / fscale))
+    a = -0.5
+    w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+    valid = taps < xmax[:, None]
+    w = np.where(valid, w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for j in range(ksize):                                                     # same left-to-right summation order as the C loop
+        ww = np.where(valid[:, j], ww + w[:, j], ww)
+    wn = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    fixed = np.where(wn < 0, (-0.5 + wn * (1 << bits)), (0.5 + wn * (1 << bits)))
+    coeffs = np.where(valid, np.trunc(fixed), 0).astype(np.int32)
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return np.ascontiguousarray(coeffs), np.ascontiguousarray(bounds)

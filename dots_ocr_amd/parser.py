@@ -57,7 +57,7 @@ class DotsOCRParser:
         from .modeling import DotsOcrHipForCausalLM
         from .processing import DotsOcrProcessor, process_vision_info
         self.model = DotsOcrHipForCausalLM.from_pretrained(self.model_path)
-        self.processor = DotsOcrProcessor.from_pretrained(self.model_path)
+        self.processor = DotsOcrProcessor.from_pretrained(self.model_path, engine=self.model.engine)   # GPU image preprocessing
         self.process_vision_info = process_vision_info
 
     def _build_inputs(self, images, prompts):

@@ -113,6 +113,16 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids_host, const int32_t* p
                   const int64_t* grid_thw_host, int n_img, int max_new_tokens,
                   const int32_t* eos_ids_host, int n_eos, int32_t* out_ids_host, int32_t* out_lens_host);
 
+/* Replaces the image half of processor.__call__ (parser.py:99-105 -> Qwen2-VL image processor: Pillow BICUBIC resize to
+ * (rh, rw) = smart_resize(h, w), x 1/255, (x - mean)/std, patchify) on the GPU, bit-identical to the host path.
+ * rgb: uint8 [h, w, 3].  The per-axis tap tables are Pillow's 22-bit fixed-point coefficients, built on the host
+ * (coef int32 [out, ksize], bounds int32 [out, 2] = first input index, tap count); pass NULL tables for an axis that
+ * is not resized.  out_pixel_values_dev: float32 [(rh/P)*(rw/P), 3*P*P] on the device, ready for dots_vit_forward. */
+int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, int h, int w, int rh, int rw,
+                          const int32_t* hcoef_host, const int32_t* hbounds_host, int hksize,
+                          const int32_t* vcoef_host, const int32_t* vbounds_host, int vksize,
+                          const float* mean3_host, const float* std3_host, float rescale, float* out_pixel_values_dev);
+
 /* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
 int dots_get_logits(DotsEngine* e, float* out_host);
 /* Teacher forcing for per-step logit comparisons: overwrite the token the next decode step feeds. */

@@ -209,3 +209,12 @@ def test_synthetic_prompt_shape():
     cfg = DotsConfig()
     ids = synth_prompt_ids(cfg, 4956)
     assert len(ids) == 5200 and int((ids == cfg.image_token_id).sum()) == 4956
+
+
+def test_bicubic_tables_match_oracle():
+    from dots_ocr_amd.image_utils import bicubic_resample_tables
+    from oracle.image_processor import pil_bicubic_coeffs
+    for (i, o) in [(1654, 1652), (2339, 2352), (100, 112), (50, 28), (36, 28), (3000, 28), (28, 700), (583, 588)]:
+        k1, b1 = pil_bicubic_coeffs(i, o)
+        k2, b2 = bicubic_resample_tables(i, o)
+        assert np.array_equal(k1, k2) and np.array_equal(b1, b2), (i, o)

@@ -230,3 +230,21 @@ def test_gemm_skinny(eng, M, N, K):
     out = torch.zeros(16, N, dtype=torch.float32, device="cuda")
     run(eng, eng.op_gemm_skinny, Xd.data_ptr(), Wd.data_ptr(), out.data_ptr(), M, N, K)
     close(out[:M], X[:M].float() @ W.float().t(), rel=1e-4, abs_=1e-4)
+
+
+@pytest.mark.parametrize("w,h", [(1654, 2339), (333, 517), (100, 40), (1344, 1344), (3000, 4200), (28, 28)])
+def test_gpu_preprocess_is_bit_identical_to_host_pillow_path(eng, w, h):
+    """uint8 page -> float32 patches on the GPU (Pillow-exact fixed-point bicubic + normalise + patchify)
+    == dots_ocr_amd.image_utils.preprocess_image, bit for bit (upscale, downscale past max_pixels, identity)."""
+    from PIL import Image
+    from dots_ocr_amd.image_utils import preprocess_image
+    rng = np.random.default_rng(w + h)
+    arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref, thw = preprocess_image(Image.fromarray(arr, "RGB"))
+    out = torch.empty(ref.shape, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    got_thw = eng.preprocess_image(arr, out.data_ptr())
+    assert got_thw == thw
+    got = out.cpu().numpy()
+    bad = got.view(np.uint32) != ref.view(np.uint32)
+    assert not bad.any(), f"{int(bad.sum())} / {bad.size} values differ, max abs diff {np.abs(got - ref).max():.3e}"

@@ -157,3 +157,13 @@ def test_vision_tower_runs_and_modes_agree():
     # images are independent: the second image alone gives the same rows
     c = om.vision_tower(sd, cfg, pv[24:], grid[1:], emulate_bf16=False)
     assert torch.allclose(c, a[6:], atol=1e-4)
+
+
+def test_fixed_point_bicubic_restatement_is_bit_exact_with_pillow():
+    """oracle.pil_bicubic_resize (the checker of the GPU preprocessing kernels) == Pillow's own BICUBIC resize."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for (w, h, rw, rh) in [(100, 40, 112, 56), (333, 517, 336, 504), (640, 36, 644, 28), (50, 50, 28, 28), (200, 300, 200, 308)]:
+        img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
+        ref = np.asarray(img.resize((rw, rh), resample=Image.BICUBIC))
+        assert np.array_equal(oip.pil_bicubic_resize(np.asarray(img), rw, rh), ref), (w, h, rw, rh)
