@@ -16,7 +16,10 @@
 // LDS: K tile [64 keys][256 B], 16-B slots XOR (key & 15); V^T tile [128 d][128 B], slots XOR
 // ((d >> 1) & 7): both fragment gathers are bank-conflict free.  Double buffered; the next tile is
 // fetched into registers before this tile's MFMAs and written to LDS after them (guide T14),
-// one barrier per tile.
+// one barrier per tile.  The loop is software-pipelined by one stage (QK of tile j and PV of tile j-1
+// form one 32-MFMA block, then the softmax of tile j); s_setprio around the MFMA blocks measured null.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -58,26 +61,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
     int n_tiles = (n + 63) >> 6;
     if (CAUSAL) n_tiles = min(n_tiles, ((qb.q0 + 127) >> 6) + 1);
 
-    // ---- staging (registers): 4 K chunks + 4 V^T chunks of 16 B per thread ----
+    // ---- staging (registers): 4 K chunks + 4 V^T chunks of 16 B per thread.  V lags K by one tile (see the loop). ----
     u32x4 kst[4], vst[4];
-    auto stage_load = [&](int j) {
+    auto load_k = [&](int j) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = it * 256 + tid;
             const int row = min(j * 64 + (item >> 4), n - 1);
             kst[it] = *reinterpret_cast<const u32x4*>(Kbase + (size_t)row * 128 + (item & 15) * 8);
-            const int d = item >> 3;
-            vst[it] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)d * Tpad + j * 64 + (item & 7) * 8);
         }
     };
-    auto stage_write = [&](int buf) {
+    auto load_v = [&](int j) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid;
+            vst[it] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)(item >> 3) * Tpad + j * 64 + (item & 7) * 8);
+        }
+    };
+    auto write_k = [&](int buf) {
         char* kb = smem + buf * BUF_BYTES;
-        char* vb = kb + KT_BYTES;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = it * 256 + tid;
             const int row = item >> 4, c = item & 15;
             *reinterpret_cast<u32x4*>(kb + row * 256 + ((c ^ (row & 15)) << 4)) = kst[it];
+        }
+    };
+    auto write_v = [&](int buf) {
+        char* vb = smem + buf * BUF_BYTES + KT_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = it * 256 + tid;
             const int d = item >> 3, cv = item & 7;
             *reinterpret_cast<u32x4*>(vb + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4)) = vst[it];
         }
@@ -89,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
+    bf16x8 pf[4];                                    // P^T of the previous tile, consumed one iteration later
 
     // fragment gather offsets (constant per lane)
     const int k_row_off = l31 * 256;                 // + kt*32*256
@@ -96,15 +111,32 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
     const int v_row_off = l31 * 128;                 // + dt*32*128
     const int v_sw = (l31 >> 1) & 7;
 
-    stage_load(0);
-    stage_write(0);
+    auto pv = [&](int buf) {                         // O^T += V^T(buf) . pf : 4 d tiles x 4 key slabs
+        const char* vb = smem + buf * BUF_BYTES + KT_BYTES;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_row_off + (((sl * 2 + hi) ^ v_sw) << 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sl], o[dt], 0, 0, 0);
+            }
+    };
+
+    load_k(0);
+    write_k(0);
     __syncthreads();
 
+    // Software-pipelined by one stage: iteration j issues ONE block of 32 MFMAs — S^T(j) = K(j).Q^T and
+    // O^T += V^T(j-1).P^T(j-1) — then runs the softmax of tile j on the VALU.  The two waves of a SIMD fall into
+    // antiphase (one in its MFMA block while the other is in its VALU block), which a strict QK -> softmax -> PV
+    // order per tile cannot do.  V(j) is staged during iteration j (it is first read in iteration j+1), K(j+1) too,
+    // so two LDS buffers and one barrier per tile still suffice:
+    //   K buffer (j+1)&1 was last read by QK(j-1), V buffer j&1 by PV(j-2) — both before the previous barrier.
     for (int j = 0; j < n_tiles; ++j) {
         const bool has_next = (j + 1 < n_tiles);
-        if (has_next) stage_load(j + 1);
+        if (has_next) load_k(j + 1);
+        load_v(j);
         const char* kb = smem + (j & 1) * BUF_BYTES;
-        const char* vb = kb + KT_BYTES;
 
         // ---- S^T = K . Q^T : 2 key tiles x 8 k-steps ----
         f32x16 s[2];
@@ -118,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
             }
         }
+        if (j > 0) pv((j - 1) & 1);
 
         // ---- mask (only the ragged last tile / the causal diagonal) ----
         const int key0 = j * 64;
@@ -144,8 +177,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // Deferred rescale (guide T13): keep the old running max while it is exceeded by at most 2^RESCALE_THR
         // for every row of the wave; P is then bounded by 2^RESCALE_THR instead of 1 (fp32 sum and bf16's 8-bit
-        // exponent have the headroom).  When the branch fires, O and l — everything still expressed against the
-        // old max — are scaled exactly once, before this tile's P is formed against the new max.
+        // exponent have the headroom).  When the branch fires, O (complete up to tile j-1: its PV was issued above)
+        // and l — everything still expressed against the old max — are scaled exactly once, before this tile's P is
+        // formed against the new max.
         const float m_cand = mx * scale_log2e;
         if (!__all(m_cand - m_run <= RESCALE_THR)) {
             const float m_new = fmaxf(m_run, m_cand);
@@ -158,7 +192,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         float psum = 0.f;
-        bf16x8 pf[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -175,18 +208,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
             }
         l_run += psum;
 
-        // ---- O^T += V^T . P^T : 4 d tiles x 4 key slabs ----
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_row_off + (((sl * 2 + hi) ^ v_sw) << 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sl], o[dt], 0, 0, 0);
-            }
-
-        if (has_next) stage_write((j + 1) & 1);
+        if (has_next) write_k((j + 1) & 1);
+        write_v(j & 1);
         __syncthreads();
     }
+    pv((n_tiles - 1) & 1);
 
     // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
