@@ -167,4 +167,20 @@ def test_full_size_model_a4_pages_deterministic_and_batch_invariant():
     assert np.array_equal(c[0], a[1])
     st = eng.stats()
     assert st["vit_patches"] == N_A4 and abs(st["vit_flops"] / 150.0e12 - 1) < 0.01      # 150.0 TFLOP per A4 page
+
+    # ragged batch at real dimensions (BASELINE configs 3-4 geometry): 1344x1344 "high-res" page (9216 patches) and a
+    # 583x550 chart-sized page (-> 588x560, 1680 patches); each page must decode as it does alone
+    from dots_ocr_amd.synthetic import HIGH_RES
+    sizes = [HIGH_RES, (583, 550)]
+    feats2, grids2 = zip(*(preprocess_image(synth_page(10 + i, sz)) for i, sz in enumerate(sizes)))
+    assert [f.shape[0] for f in feats2] == [9216, 1680]          # 2304 and 420 vision tokens (SURVEY §4 fixtures)
+    pv2, grid2 = np.concatenate(feats2, 0), np.asarray(grids2, np.int64)
+    prompts2 = [synth_prompt_ids(cfg, f.shape[0] // 4, n_text_tokens=37 + 11 * i, seed=20 + i) for i, f in enumerate(feats2)]
+    lens2 = np.array([len(p) for p in prompts2], np.int32)
+    m, _ = eng.generate(np.concatenate(prompts2), lens2, pv2, grid2, max_new_tokens=6)
+    off = 0
+    for i, f in enumerate(feats2):
+        single, _ = eng.generate(prompts2[i], lens2[i:i + 1], f, grid2[i:i + 1], max_new_tokens=6)
+        assert np.array_equal(single[0], m[i]), i
+        off += f.shape[0]
     eng.close()
