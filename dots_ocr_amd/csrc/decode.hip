@@ -338,6 +338,111 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Temperature / nucleus (top-p) sampling step (the reference's vLLM path samples at T = 0.1, top_p = 1.0,
+// parser.py:27-28; SVG at T = 0.9, demo_vllm_svg.py:35-36).  One workgroup per sequence, no sort:
+//   e_i = exp((l_i - max) / T);  nucleus = largest threshold tau with  sum_{e_i >= tau} e_i >= top_p * sum_i e_i
+//   (28 bisection steps on tau);  token = inverse CDF of u * mass over the kept e_i in index order.
+// u comes from a counter-based hash of (seed, sequence slot, position), so a run is reproducible from its seed.
+constexpr int SAMPLE_THREADS = 1024;
+
+DEVI float block_reduce_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMPLE_THREADS / 64; ++i) t += red[i];
+    return t;
+}
+DEVI float block_reduce_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < SAMPLE_THREADS / 64; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+DEVI uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float* __restrict__ logits, int V, int ld, float inv_temp,
+                                                                     float top_p, uint64_t seed, int32_t* __restrict__ cur_tokens,
+                                                                     int32_t* __restrict__ ctx_len, int32_t* __restrict__ out_ids,
+                                                                     int32_t* __restrict__ out_lens, int32_t* __restrict__ finished,
+                                                                     const int32_t* __restrict__ eos_ids, int n_eos, int max_new_tokens,
+                                                                     int advance_ctx) {
+    __shared__ float red[SAMPLE_THREADS / 64];
+    __shared__ float scan[SAMPLE_THREADS];
+    __shared__ int chosen;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (size_t)b * ld;
+    const int C = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;         // contiguous chunk per thread: index order is preserved
+    const int lo = tid * C, hi = min(V, lo + C);
+    float mx = -INFINITY;
+    for (int i = lo; i < hi; ++i) mx = fmaxf(mx, row[i]);
+    mx = block_reduce_max(mx, red);
+    float z = 0.f;
+    for (int i = lo; i < hi; ++i) z += __expf((row[i] - mx) * inv_temp);
+    z = block_reduce_sum(z, red);
+    float tau = 0.f;
+    if (top_p < 1.0f) {
+        float lo_t = 0.f, hi_t = 1.0f;                               // mass(lo_t) >= target always, mass(hi_t = 1) may not be
+        const float target = top_p * z;
+        for (int it = 0; it < 28; ++it) {
+            const float mid = 0.5f * (lo_t + hi_t);
+            float mass = 0.f;
+            for (int i = lo; i < hi; ++i) { const float e = __expf((row[i] - mx) * inv_temp); mass += e >= mid ? e : 0.f; }
+            mass = block_reduce_sum(mass, red);
+            if (mass >= target) lo_t = mid; else hi_t = mid;
+        }
+        tau = lo_t;
+    }
+    float part = 0.f;
+    for (int i = lo; i < hi; ++i) { const float e = __expf((row[i] - mx) * inv_temp); part += e >= tau ? e : 0.f; }
+    scan[tid] = part;
+    __syncthreads();
+    if (tid == 0) {                                                   // serial scan of 1024 partials: ~1 us, once per step
+        const int pos = out_lens[b];
+        const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)b << 32) | (uint32_t)pos));
+        const float u = (float)(h >> 40) * (1.0f / 16777216.0f);     // [0, 1)
+        float total = 0.f;
+        for (int t = 0; t < SAMPLE_THREADS; ++t) total += scan[t];
+        const float x = u * total;
+        float acc = 0.f;
+        int t = 0;
+        for (; t < SAMPLE_THREADS - 1; ++t) { if (acc + scan[t] > x) break; acc += scan[t]; }
+        int tok = -1;
+        const int l2 = t * C, h2 = min(V, l2 + C);
+        for (int i = l2; i < h2; ++i) {
+            const float e = __expf((row[i] - mx) * inv_temp);
+            if (e >= tau) { tok = i; acc += e; if (acc > x) break; }
+        }
+        if (tok < 0) {                                                // numerical corner: fall back to the arg max
+            float best = -INFINITY;
+            for (int i = 0; i < V; ++i) if (row[i] > best) { best = row[i]; tok = i; }
+        }
+        chosen = tok;
+        if (advance_ctx) ctx_len[b] += 1;
+        if (!finished[b]) {
+            const int n = out_lens[b];
+            out_ids[(size_t)b * max_new_tokens + n] = tok;
+            out_lens[b] = n + 1;
+            bool eos = false;
+            for (int k = 0; k < n_eos; ++k) eos = eos || (tok == eos_ids[k]);
+            if (eos || n + 1 >= max_new_tokens) finished[b] = 1;
+        }
+        cur_tokens[b] = tok;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
@@ -387,5 +492,14 @@ hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld,
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_CHUNKS, B), dim3(256), 0, s, logits, V, ld, pval, pidx);
     hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, cur_tokens, ctx_len, out_ids, out_lens,
                        finished, eos_ids, n_eos, max_new_tokens, advance_ctx);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_step(hipStream_t s, const float* logits, int V, int ld, int B, float temperature, float top_p, uint64_t seed,
+                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
+                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx) {
+    if (temperature <= 0.f || top_p <= 0.f) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(SAMPLE_THREADS), 0, s, logits, V, ld, 1.0f / temperature, fminf(top_p, 1.0f), seed,
+                       cur_tokens, ctx_len, out_ids, out_lens, finished, eos_ids, n_eos, max_new_tokens, advance_ctx);
     return hipGetLastError();
 }

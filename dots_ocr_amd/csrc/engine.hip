@@ -138,10 +138,13 @@ struct DotsEngine {
             *finished = nullptr, *eos_ids = nullptr, *am_idx = nullptr;
     float* am_val = nullptr;
     int n_eos = 0;
+    float temperature = 0.f, top_p = 1.f;      // temperature <= 0: greedy (arg max)
+    uint64_t seed = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
     bf16_t *d_h = nullptr, *d_h2 = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
     float *d_slabs = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     int B = 0;                             // sequences of the current batch
+    int B_sel = 0;                         // rows the token-selection kernel runs over
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
 
@@ -531,6 +534,19 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     return DOTS_OK;
 }
 
+// greedy arg max or temperature / top-p sampling over the fp32 logits of the step
+int select_tokens(DotsEngine* e, int advance) {
+    const DotsConfig& c = e->cfg;
+    if (e->temperature > 0.f) {
+        CK(launch_sample_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->temperature, e->top_p, e->seed, e->cur_tokens,
+                              e->ctx_len, e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, advance));
+    } else {
+        CK(launch_argmax_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
+                              e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, advance));
+    }
+    return DOTS_OK;
+}
+
 int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
@@ -590,8 +606,8 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, e->d_h, B, H));
     CK(launch_dec_lmhead(s, e->d_h, nullptr, 0, nullptr, e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
-    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
-                          e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 0));
+    e->B_sel = B;
+    RET(select_tokens(e, 0));
     CK(hipEventRecord(e->ev[3], s));
     e->B = B;
     e->h_prompt_lens = L;
@@ -633,8 +649,8 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
         n_slabs = down_split > 1 ? down_split : 0;
     }
     CK(launch_dec_lmhead(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
-    CK(launch_argmax_step(s, e->d_logits, c.vocab_size, c.vocab_size, B, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
-                          e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, 1));
+    e->B_sel = B;
+    RET(select_tokens(e, 1));
     return DOTS_OK;
 }
 
@@ -911,6 +927,15 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int on_device, int 
     }
     CK(launch_normalize_patchify(s, src, out, rw, rh / P, rw / P, P, m, rescale, mean3, std3));
     CK(hipStreamSynchronize(s));          // the host tables / image buffers may be reused by the caller
+    return DOTS_OK;
+}
+
+int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed) {
+    if (!e) return DOTS_E_INVALID;
+    if (!(temperature >= 0.f) || !(top_p > 0.f)) return e->fail(DOTS_E_INVALID, "temperature must be >= 0 and top_p in (0, 1]");
+    e->temperature = temperature;
+    e->top_p = top_p > 1.f ? 1.f : top_p;
+    e->seed = seed;
     return DOTS_OK;
 }
 

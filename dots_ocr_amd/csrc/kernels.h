@@ -62,6 +62,9 @@ hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const 
 hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx,
                               int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
                               const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx);
+hipError_t launch_sample_step(hipStream_t s, const float* logits, int V, int ld, int B, float temperature, float top_p, uint64_t seed,
+                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
+                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx);
 // row-major [rows, K] -> MFMA fragment order (decode.hip): 16-row tiles x K/32 chunks of 1 KiB
 hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K);
 // ---- engine.hip helper kernels

@@ -68,6 +68,7 @@ def _prototypes(lib):
         "dots_decode_step": (i32, [vp]),
         "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
         "dots_preprocess_image": (i32, [vp, vp, i32, i32, i32, i32, i32, P(i32), P(i32), i32, P(i32), P(i32), i32, P(f32), P(f32), f32, vp]),
+        "dots_set_sampling": (i32, [vp, f32, f32, C.c_uint64]),
         "dots_get_logits": (i32, [vp, P(f32)]),
         "dots_set_next_tokens": (i32, [vp, P(i32), i32]),
         "dots_get_last_tokens": (i32, [vp, P(i32)]),
@@ -94,7 +95,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_get_logits",
+    "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_get_logits",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma",
@@ -248,6 +249,10 @@ class Engine:
         assert ids.shape[0] == int(lens.sum())
         self._ck(self.lib.dots_prefill(self.h, _i32p(ids), _i32p(lens), lens.shape[0]), "dots_prefill")
         self._B = int(lens.shape[0])
+
+    def set_sampling(self, temperature: float = 0.0, top_p: float = 1.0, seed: int = 0):
+        """temperature 0 = greedy; otherwise softmax(logits/T) restricted to the top_p nucleus, reproducible from seed."""
+        self._ck(self.lib.dots_set_sampling(self.h, float(temperature), float(top_p), int(seed) & (2 ** 64 - 1)), "dots_set_sampling")
 
     def decode_step(self):
         self._ck(self.lib.dots_decode_step(self.h), "dots_decode_step")

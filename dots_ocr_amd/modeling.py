@@ -59,12 +59,16 @@ class DotsOcrHipForCausalLM:
 
     # ------------------------------------------------------------------ generate
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
-                 max_new_tokens: int = 128, do_sample: bool = False, eos_token_id=None, pad_token_id=None, **_):
-        """HF-shaped greedy generate.  Returns LongTensor [B, T + n]: the (padded) prompt followed by the new
-        tokens, positions after a sequence's EOS filled with pad_token_id."""
+                 max_new_tokens: int = 128, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
+                 seed: int = 0, eos_token_id=None, pad_token_id=None, **_):
+        """HF-shaped generate.  Greedy by default (do_sample=False); with do_sample=True tokens are drawn on the GPU from
+        softmax(logits / temperature) restricted to the top_p nucleus, reproducibly from `seed`.  Returns LongTensor
+        [B, T + n]: the (padded) prompt followed by the new tokens, positions after a sequence's EOS filled with pad_token_id."""
         import torch
-        if do_sample:
-            raise NotImplementedError("the HIP engine decodes greedily (do_sample=False)")
+        if do_sample and temperature > 0:
+            self.engine.set_sampling(temperature, top_p, seed)
+        else:
+            self.engine.set_sampling(0.0, 1.0, 0)
         ids = input_ids.detach().cpu().numpy()
         B, T = ids.shape
         mask = attention_mask.detach().cpu().numpy().astype(bool) if attention_mask is not None else np.ones_like(ids, bool)

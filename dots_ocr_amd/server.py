@@ -1,0 +1,205 @@
+"""OpenAI-compatible `/v1/chat/completions` endpoint on top of the HIP engine.
+
+The reference's DEFAULT backend is an HTTP client of a vLLM server (dots_ocr/model/inference.py:7-48, used by
+`DotsOCRParser(use_hf=False)`, demo/demo_vllm*.py and the Gradio/Streamlit apps): it POSTs one user message holding an
+`image_url` data URL (base64 PNG, image_utils.py:67-71) and a text part "<|img|><|imgpad|><|endofimg|>{prompt}", with
+`max_completion_tokens`, `temperature`, `top_p` (inference.py:28-43), and reads `choices[0].message.content`.  This module
+serves exactly that wire format from the MI355X engine, so those callers work unchanged when pointed at it:
+
+    python -m dots_ocr_amd.server --model-path ./weights/DotsOCR --port 8000
+
+Concurrent requests (the reference client uses a ThreadPool of up to 64, parser.py:286-290) are collected by a batching
+worker into engine batches of up to `max_batch` pages with the same sampling parameters.
+"""
+from __future__ import annotations
+
+import argparse
+import queue
+import threading
+import time
+import uuid
+from concurrent.futures import Future
+from typing import List, Optional
+
+from .image_utils import fetch_image
+from .processing import ASSISTANT, END_USER, IMG_END, IMG_PAD, IMG_START, USER
+
+
+class _Job:
+    __slots__ = ("image", "text", "max_tokens", "temperature", "top_p", "future")
+
+    def __init__(self, image, text, max_tokens, temperature, top_p):
+        self.image, self.text, self.max_tokens, self.temperature, self.top_p = image, text, max_tokens, temperature, top_p
+        self.future: Future = Future()
+
+
+class BatchingWorker:
+    """Single consumer thread (the engine handle is not thread-safe): groups queued jobs by sampling parameters."""
+
+    def __init__(self, model, processor, max_batch: int = 8, max_wait_ms: float = 5.0, seed: int = 0):
+        self.model, self.processor = model, processor
+        self.max_batch, self.max_wait = max_batch, max_wait_ms / 1e3
+        self.q: "queue.Queue[_Job]" = queue.Queue()
+        self.seed = seed
+        self.batches: List[int] = []            # sizes of the executed batches (observability / tests)
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, name="dots-ocr-batcher", daemon=True)
+        self.thread.start()
+
+    def submit(self, job: _Job) -> Future:
+        self.q.put(job)
+        return job.future
+
+    def close(self):
+        self._stop = True
+        self.q.put(None)
+        self.thread.join(timeout=5)
+
+    def _run(self):
+        pending: List[_Job] = []
+        while not self._stop:
+            if not pending:
+                job = self.q.get()
+                if job is None:
+                    return
+                pending.append(job)
+            deadline = time.monotonic() + self.max_wait
+            while len(pending) < 4 * self.max_batch:
+                try:
+                    job = self.q.get(timeout=max(0.0, deadline - time.monotonic()))
+                except queue.Empty:
+                    break
+                if job is None:
+                    self._stop = True
+                    break
+                pending.append(job)
+            key = (pending[0].max_tokens, pending[0].temperature, pending[0].top_p)
+            batch = [j for j in pending if (j.max_tokens, j.temperature, j.top_p) == key][: self.max_batch]
+            pending = [j for j in pending if j not in batch]
+            self._execute(batch)
+
+    def _execute(self, batch: List[_Job]):
+        try:
+            images = [j.image for j in batch if j.image is not None]
+            inputs = self.processor(text=[j.text for j in batch], images=images or None, padding=True, return_tensors="pt")
+            j0 = batch[0]
+            self.seed += 1
+            out = self.model.generate(**inputs, max_new_tokens=j0.max_tokens, do_sample=j0.temperature > 0,
+                                      temperature=j0.temperature, top_p=j0.top_p, seed=self.seed)
+            new = [o[len(i):] for i, o in zip(inputs.input_ids, out)]
+            texts = self.processor.batch_decode(new, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+            pad = self.processor.tokenizer.pad_token_id
+            eos = set(getattr(self.model, "config", None).eos_token_ids) if getattr(self.model, "config", None) else set()
+            self.batches.append(len(batch))
+            for j, t, ids, inp in zip(batch, texts, new, inputs.input_ids):
+                toks = [int(x) for x in ids.tolist()]
+                while toks and toks[-1] == pad and pad not in eos:
+                    toks.pop()
+                n_new = len(toks)
+                hit_eos = any(x in eos for x in toks)
+                j.future.set_result({"text": t, "prompt_tokens": int((inp != pad).sum()) if pad not in eos else int(len(inp)),
+                                     "completion_tokens": n_new, "finish_reason": "stop" if hit_eos else "length"})
+        except Exception as e:                      # surface the failure to every waiting request
+            for j in batch:
+                if not j.future.done():
+                    j.future.set_exception(e)
+
+
+def _parse_messages(messages):
+    """OpenAI chat messages -> (PIL image or None, chat-template text).  The reference client writes the image
+    placeholder tokens into its text part itself (model/inference.py:33); if they are missing they are added."""
+    image, parts, system = None, [], ""
+    for m in messages:
+        content = m.get("content")
+        if m.get("role") == "system":
+            system += content if isinstance(content, str) else "".join(c.get("text", "") for c in content)
+            continue
+        if isinstance(content, str):
+            parts.append(content)
+            continue
+        for c in content or []:
+            if c.get("type") == "image_url":
+                url = c["image_url"]["url"] if isinstance(c["image_url"], dict) else c["image_url"]
+                image = fetch_image(url)
+            elif c.get("type") == "text":
+                parts.append(c["text"])
+    body = "".join(parts)
+    if image is not None and IMG_PAD not in body:
+        body = IMG_START + IMG_PAD + IMG_END + body
+    return image, system + USER + body + END_USER + ASSISTANT
+
+
+def create_app(model, processor, model_name: str = "model", max_batch: int = 8, max_wait_ms: float = 5.0):
+    from fastapi import FastAPI, HTTPException
+    from fastapi.concurrency import run_in_threadpool
+
+    app = FastAPI(title="dots.ocr MI355X engine")
+    worker = BatchingWorker(model, processor, max_batch=max_batch, max_wait_ms=max_wait_ms)
+    app.state.worker = worker
+
+    @app.get("/health")
+    def health():
+        return {"status": "ok"}
+
+    @app.get("/v1/models")
+    def models():
+        return {"object": "list", "data": [{"id": model_name, "object": "model", "owned_by": "dots_ocr_amd"}]}
+
+    @app.post("/v1/chat/completions")
+    async def chat(req: dict):
+        if req.get("stream"):
+            raise HTTPException(400, "streaming is not supported")
+        messages = req.get("messages")
+        if not messages:
+            raise HTTPException(400, "messages is required")
+        try:
+            image, text = _parse_messages(messages)
+        except Exception as e:
+            raise HTTPException(400, f"bad message content: {e}")
+        max_tokens = int(req.get("max_completion_tokens") or req.get("max_tokens") or 16384)
+        temperature = float(req.get("temperature", 1.0) if req.get("temperature") is not None else 1.0)
+        top_p = float(req.get("top_p", 1.0) if req.get("top_p") is not None else 1.0)
+        fut = worker.submit(_Job(image, text, max_tokens, max(0.0, temperature), min(max(top_p, 1e-6), 1.0)))
+        try:
+            res = await run_in_threadpool(fut.result)
+        except Exception as e:
+            raise HTTPException(500, f"generation failed: {e}")
+        return {
+            "id": "chatcmpl-" + uuid.uuid4().hex, "object": "chat.completion", "created": int(time.time()),
+            "model": req.get("model", model_name),
+            "choices": [{"index": 0, "message": {"role": "assistant", "content": res["text"]}, "finish_reason": res["finish_reason"]}],
+            "usage": {"prompt_tokens": res["prompt_tokens"], "completion_tokens": res["completion_tokens"],
+                      "total_tokens": res["prompt_tokens"] + res["completion_tokens"]},
+        }
+
+    @app.on_event("shutdown")
+    def _shutdown():
+        worker.close()
+
+    return app
+
+
+def main(argv: Optional[List[str]] = None):
+    ap = argparse.ArgumentParser(description="OpenAI-compatible server for the dots.ocr MI355X engine")
+    ap.add_argument("--model-path", default="./weights/DotsOCR")
+    ap.add_argument("--random-weights", action="store_true", help="seeded random weights (no checkpoint): plumbing tests only")
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--served-model-name", default="model")
+    ap.add_argument("--max-batch", type=int, default=8)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    import uvicorn
+    from .modeling import DotsOcrHipForCausalLM
+    from .processing import DotsOcrProcessor
+    if a.random_weights:
+        model = DotsOcrHipForCausalLM.from_random(device=a.device, max_batch=a.max_batch)
+        proc = DotsOcrProcessor(model.config, engine=model.engine)
+    else:
+        model = DotsOcrHipForCausalLM.from_pretrained(a.model_path, device=a.device, max_batch=a.max_batch)
+        proc = DotsOcrProcessor.from_pretrained(a.model_path, engine=model.engine)
+    uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch), host=a.host, port=a.port)
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,12 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, 
                           const int32_t* vcoef_host, const int32_t* vbounds_host, int vksize,
                           const float* mean3_host, const float* std3_host, float rescale, float* out_pixel_values_dev);
 
+/* Token selection for the following prefill / decode / generate calls.  temperature == 0 (default): greedy arg max.
+ * temperature > 0: sample from softmax(logits / temperature) restricted to the top_p nucleus — the sampling
+ * parameters the reference passes to its vLLM backend (parser.py:27-28, model/inference.py:38-43).  Reproducible
+ * from `seed` (counter-based: seed, batch slot, position). */
+int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed);
+
 /* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
 int dots_get_logits(DotsEngine* e, float* out_host);
 /* Teacher forcing for per-step logit comparisons: overwrite the token the next decode step feeds. */

@@ -189,3 +189,56 @@ def test_batch_of_more_than_8_rows_uses_full_mfma_columns():
                                  max_new_tokens=10)
         assert np.array_equal(single[0], out[b]), b
     eng.close()
+
+
+def test_sampling_matches_softmax_and_respects_nucleus(setup):
+    """Temperature / top-p sampling on the GPU: limits, reproducibility, distribution, nucleus."""
+    cfg, sd, eng = setup
+    pv, grid, seqs = _inputs(cfg, [(1, 4, 4)], 6, seed=8)
+    ids = seqs[0].numpy().astype(np.int32)
+    lens = np.array([len(ids)], np.int32)
+    eng.set_sampling(0.0, 1.0, 0)
+    greedy, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=8)
+    # (a) T -> 0 and a tiny nucleus both collapse to the arg max
+    eng.set_sampling(1e-3, 1.0, 123)
+    cold, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=8)
+    eng.set_sampling(1.0, 1e-4, 123)
+    narrow, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=8)
+    assert np.array_equal(cold, greedy) and np.array_equal(narrow, greedy)
+    # (b) reproducible from the seed; another seed gives another continuation at T = 1.5
+    eng.set_sampling(1.5, 1.0, 7)
+    a, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=16)
+    b, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=16)
+    eng.set_sampling(1.5, 1.0, 8)
+    c, _ = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=16)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    # (c) first-token distribution over many seeds == softmax(logits / T) (prefill logits are deterministic)
+    T = 2.0
+    eng.vit_forward(pv.numpy(), grid.numpy())
+    eng.set_sampling(0.0, 1.0, 0)
+    eng.prefill(ids, lens)
+    logits = torch.from_numpy(eng.get_logits())[0].double()
+    p = torch.softmax(logits / T, -1)
+    n = 3000
+    counts = torch.zeros(cfg.vocab_size)
+    for seed in range(n):
+        eng.set_sampling(T, 1.0, 1000 + seed)
+        eng.vit_forward(pv.numpy(), grid.numpy())
+        eng.prefill(ids, lens)
+        counts[int(eng.get_last_tokens()[0])] += 1
+    top = torch.topk(p, 8).indices
+    for t in top.tolist():
+        exp, got = float(p[t]) * n, float(counts[t])
+        assert abs(got - exp) < 5 * (exp ** 0.5) + 3, (t, exp, got)          # 5 sigma of a binomial
+    # (d) nucleus: every sample lies in the smallest set of top tokens whose mass reaches top_p
+    top_p = 0.3
+    order = torch.argsort(p, descending=True)
+    csum = torch.cumsum(p[order], 0)
+    k = int((csum < top_p).sum()) + 1
+    nucleus = set(order[:k + 1].tolist())                                     # +1: tie / fp slack at the boundary
+    for seed in range(300):
+        eng.set_sampling(T, top_p, 5000 + seed)
+        eng.vit_forward(pv.numpy(), grid.numpy())
+        eng.prefill(ids, lens)
+        assert int(eng.get_last_tokens()[0]) in nucleus
+    eng.set_sampling(0.0, 1.0, 0)
