@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         obj = OBJ / (src.name + ".o")
         objs.append(obj)
         if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_m):
-            cmd = [cc, *CXXFLAGS, "-x", "hip", "-c", str(src), "-o", str(obj)]
+            cmd = [cc, *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", str(src), "-o", str(obj)]
             jobs.append((src, cmd))
 
     def run(job):
@@ -76,8 +76,13 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             for src, p in ex.map(run, jobs):
                 if p.returncode != 0:
                     raise RuntimeError(f"hipcc failed on {src.name}:\n{p.stdout}\n{p.stderr}")
-                if verbose and p.stderr.strip():
-                    print(p.stderr, file=sys.stderr)
+                # per-kernel register / LDS / scratch report (tests/test_cabi_cpu.py asserts that nothing spills)
+                usage = [ln for ln in p.stderr.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" in ln]
+                (OBJ / (src.name + ".resusage.txt")).write_text("\n".join(usage) + "\n")
+                rest = [ln for ln in p.stderr.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" not in ln
+                        and "remark" not in ln and ln.strip() and not ln.startswith(" ") and "generated" not in ln]
+                if verbose and rest:
+                    print("\n".join(rest), file=sys.stderr)
     out = lib_path()
     if jobs or not out.exists():
         cmd = [cc, f"--offload-arch={ARCH}", *LDFLAGS, *map(str, objs), "-o", str(out)]

@@ -381,7 +381,6 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float
                                                                      int advance_ctx) {
     __shared__ float red[SAMPLE_THREADS / 64];
     __shared__ float scan[SAMPLE_THREADS];
-    __shared__ int chosen;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (size_t)b * ld;
     const int C = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;         // contiguous chunk per thread: index order is preserved
@@ -429,7 +428,6 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float
             float best = -INFINITY;
             for (int i = 0; i < V; ++i) if (row[i] > best) { best = row[i]; tok = i; }
         }
-        chosen = tok;
         if (advance_ctx) ctx_len[b] += 1;
         if (!finished[b]) {
             const int n = out_lens[b];

@@ -105,6 +105,25 @@ DEVI f32x4 stream_tile(const bf16x8* __restrict__ wp, const bf16x8* xp, int xstr
     return acc0 + acc1;
 }
 
+// Same contraction for slices of <= 8 k-steps per round WITHOUT the next-group prefetch registers (the 16-wave qkv
+// workgroup is capped at 128 VGPRs; its slices are 6 k-steps at H = 1536, so one round is the whole slice).
+DEVI f32x4 stream_tile_lean(const bf16x8* __restrict__ wp, const bf16x8* xp, int xstride, int k0, int k1, bf16x8 (&a)[8]) {
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    for (int ks = k0; ks < k1; ks += 8) {
+        if (ks != k0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (ks + j < k1) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            if (ks + j < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], xp[(size_t)(ks + j) * xstride], acc0, 0, 0, 0);
+            if (ks + j + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], xp[(size_t)(ks + j + 1) * xstride], acc1, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restrict__ tokens, const bf16_t* __restrict__ embed,
                                                         bf16_t* __restrict__ h, int dim) {
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     }
     norm_rows_to_lds(h, slabs, n_slabs, h_out, ln_w, B, H, eps, xs, XR, wv, 16, lane);
     __syncthreads();
-    red[wv * 64 + lane] = stream_tile(wp, reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1)), 4 * XR, k0, k1, a0);
+    red[wv * 64 + lane] = stream_tile_lean(wp, reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1)), 4 * XR, k0, k1, a0);
     __syncthreads();
     if (wv != 0) return;
     f32x4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
@@ -221,7 +240,8 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // act = silu(gate) * up with gate/up = rmsnorm(h) @ W13^T.  grid I/16 workgroups x GU_WAVES waves (K-slices);
 // workgroup = one (gate tile, up tile) pair of the packed W13 (64-row groups: 32 gate rows | 32 up rows).
-// The first group of weight chunks (4 gate + 4 up = 8 KiB per wave) is issued before the norm prologue.
+
+constexpr int GU_G = 12;         // k-steps per wave held in registers (H = 1536: 48 k-steps / 4 waves)
 constexpr int GU_WAVES = 4;     // 12 (single round) was measured slower: 12 waves x 49 KB LDS leaves 560 workgroups non-resident
 
 __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
@@ -238,9 +258,11 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     const int xstride = 4 * XR;
     const bf16x8* wg = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + a) * KS) * 64 + lane;
     const bf16x8* wu = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + 2 + a) * KS) * 64 + lane;
-    bf16x8 a_[4], u_[4];
+    // the wave's WHOLE K-slice (<= GU_G k-steps x (gate, up) = 24 KiB) is in flight before (and under) the norm prologue:
+    // one HBM round trip per wave instead of three
+    bf16x8 a_[GU_G], u_[GU_G];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < GU_G; ++j)
         if (k0 + j < k1) {
             a_[j] = __builtin_nontemporal_load(wg + (size_t)(k0 + j) * 64);
             u_[j] = __builtin_nontemporal_load(wu + (size_t)(k0 + j) * 64);
@@ -248,25 +270,22 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     norm_rows_to_lds(h, nullptr, 0, nullptr, ln_w, B, H, eps, xs, XR, wv, GU_WAVES, lane);
     __syncthreads();
     f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
-    for (int ks = k0; ks < k1; ks += 4) {          // one trip when KS <= 4 * GU_WAVES
-        bf16x8 b_[4], an[4], un[4];
+    for (int ks = k0; ks < k1; ks += GU_G) {       // one trip when the slice fits (H <= 1536)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ks + j < k1) b_[j] = xp[(size_t)(ks + j) * xstride];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ks + 4 + j < k1) {
-                an[j] = __builtin_nontemporal_load(wg + (size_t)(ks + 4 + j) * 64);
-                un[j] = __builtin_nontemporal_load(wu + (size_t)(ks + 4 + j) * 64);
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < GU_G; ++j)
             if (ks + j < k1) {
-                ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[j], b_[j], ag, 0, 0, 0);
-                au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[j], b_[j], au, 0, 0, 0);
+                const bf16x8 b = xp[(size_t)(ks + j) * xstride];
+                ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[j], b, ag, 0, 0, 0);
+                au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[j], b, au, 0, 0, 0);
             }
+        if (ks + GU_G < k1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a_[j] = an[j]; u_[j] = un[j]; }
+            for (int j = 0; j < GU_G; ++j)
+                if (ks + GU_G + j < k1) {
+                    a_[j] = __builtin_nontemporal_load(wg + (size_t)(ks + GU_G + j) * 64);
+                    u_[j] = __builtin_nontemporal_load(wu + (size_t)(ks + GU_G + j) * 64);
+                }
+        }
     }
     red[(wv * 2) * 64 + lane] = ag;
     red[(wv * 2 + 1) * 64 + lane] = au;

@@ -70,3 +70,23 @@ def test_product_never_imports_oracle():
         for f in (ROOT / pkg).rglob("*.py"):
             src = f.read_text()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_no_kernel_spills_registers_or_uses_scratch():
+    """Every gfx950 kernel must fit its register budget: a spill means scratch traffic in a hot loop (and the 16-wave decode
+    workgroups sit right at the 128-VGPR cap).  build.py saves hipcc's -Rpass-analysis=kernel-resource-usage report per source."""
+    from dots_ocr_amd import build
+    build.build(force=not list((build.OBJ).glob("*.resusage.txt")), verbose=False)
+    reports = list(build.OBJ.glob("*.resusage.txt"))
+    assert len(reports) >= 8
+    kernels = 0
+    for rep in reports:
+        name = None
+        for ln in rep.read_text().splitlines():
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                name, kernels = m.group(1), kernels + 1
+            m = re.search(r"(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", ln)
+            if m:
+                assert int(m.group(2)) == 0, f"{rep.name}: {name}: {m.group(1)} = {m.group(2)}"
+    assert kernels >= 40

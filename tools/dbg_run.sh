@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp; ulimit -c 0
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+timeout 200 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -3
+timeout 150 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/dbg.out 2> $R/gpurun_out/dbg.err; echo rc=$?
+python -c "
+import json; d=json.load(open('$R/gpurun_out/dbg.out')); print(d['value'], d['phase_ms_per_step'], d['roofline_decode']['ms_per_decode_step'])"; grep -v amdgpu.ids $R/gpurun_out/dbg.err | tail -3
