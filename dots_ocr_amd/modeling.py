@@ -22,7 +22,7 @@ from .weights import load_state_dict, random_state_dict
 
 
 class DotsOcrHipForCausalLM:
-    def __init__(self, cfg: DotsConfig, state_dict, device: int = 0, max_batch: int = 8, max_seq_len: int = 8192,
+    def __init__(self, cfg: DotsConfig, state_dict, device: int = 0, max_batch: int = 8, max_seq_len: int = 32768,
                  max_patches: Optional[int] = None):
         self.config = cfg
         self.device_index = device
@@ -104,6 +104,12 @@ class DotsOcrHipForCausalLM:
             else:
                 pv_host = np.ascontiguousarray(pixel_values.detach().numpy(), dtype=np.float32)
 
+        # like HF, generation stops at the context capacity instead of failing: the reference asks for 24 000 new tokens
+        # (parser.py:110) on top of prompts of up to 14 400 vision tokens; the KV pool is sized for max_seq_len per sequence
+        longest = max(len(p) for p in prompts)
+        if longest >= self.max_seq_len:
+            raise ValueError(f"prompt of {longest} tokens does not fit max_seq_len={self.max_seq_len}")
+        max_new_tokens = max(1, min(int(max_new_tokens), self.max_seq_len - longest))
         new_tokens = np.full((B, max_new_tokens), pad, dtype=np.int64)
         n_max = 0
         for s in range(0, B, self.max_batch):                       # static batches of <= max_batch sequences
