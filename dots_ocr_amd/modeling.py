@@ -21,6 +21,23 @@ from .engine import Engine
 from .weights import load_state_dict, random_state_dict
 
 
+def plan_batches(patches_per_seq: Sequence[int], max_batch: int, max_patches: int):
+    """Consecutive sequences -> engine batches of <= max_batch sequences and <= max_patches vision patches (ViT workspace).
+    A single sequence larger than the patch budget is rejected (it cannot be split: attention spans the whole image)."""
+    batches, cur, used = [], [], 0
+    for i, n in enumerate(patches_per_seq):
+        if n > max_patches:
+            raise ValueError(f"sequence {i} has {n} vision patches, more than the engine's max_patches={max_patches}")
+        if cur and (len(cur) == max_batch or used + n > max_patches):
+            batches.append(cur)
+            cur, used = [], 0
+        cur.append(i)
+        used += n
+    if cur:
+        batches.append(cur)
+    return batches
+
+
 class DotsOcrHipForCausalLM:
     def __init__(self, cfg: DotsConfig, state_dict, device: int = 0, max_batch: int = 8, max_seq_len: int = 32768,
                  max_patches: Optional[int] = None):
@@ -31,6 +48,7 @@ class DotsOcrHipForCausalLM:
         self.engine.load_state_dict(state_dict)
         self.max_batch = max_batch
         self.max_seq_len = max_seq_len
+        self.max_patches = max_patches
         self.generation_config = {"do_sample": False, "eos_token_id": list(cfg.eos_token_ids), "pad_token_id": cfg.pad_token_id}
 
     # ------------------------------------------------------------------ constructors
@@ -112,8 +130,8 @@ class DotsOcrHipForCausalLM:
         max_new_tokens = max(1, min(int(max_new_tokens), self.max_seq_len - longest))
         new_tokens = np.full((B, max_new_tokens), pad, dtype=np.int64)
         n_max = 0
-        for s in range(0, B, self.max_batch):                       # static batches of <= max_batch sequences
-            sl = list(range(s, min(B, s + self.max_batch)))
+        seq_patches = [int(sum(patch_off[g + 1] - patch_off[g] for g in img_of_seq[b])) for b in range(B)]
+        for sl in plan_batches(seq_patches, self.max_batch, self.max_patches):     # static batches within the engine's capacity
             imgs = [g for b in sl for g in img_of_seq[b]]
             lens = np.array([len(prompts[b]) for b in sl], np.int32)
             packed = np.concatenate([prompts[b] for b in sl])

@@ -218,3 +218,13 @@ def test_bicubic_tables_match_oracle():
         k1, b1 = pil_bicubic_coeffs(i, o)
         k2, b2 = bicubic_resample_tables(i, o)
         assert np.array_equal(k1, k2) and np.array_equal(b1, b2), (i, o)
+
+
+def test_plan_batches_respects_sequence_and_patch_budgets():
+    from dots_ocr_amd.modeling import plan_batches
+    assert plan_batches([19824] * 8, 8, 8 * 19824 + 64) == [list(range(8))]
+    assert plan_batches([57600] * 3, 8, 158656) == [[0, 1], [2]]                  # max-res pages: patch budget splits the batch
+    assert plan_batches([10] * 5, 2, 1000) == [[0, 1], [2, 3], [4]]
+    assert plan_batches([0, 0, 0], 8, 100) == [[0, 1, 2]]                           # text-only prompts
+    with pytest.raises(ValueError):
+        plan_batches([200], 8, 100)
