@@ -2,7 +2,7 @@
 // biggest cost of a page) and causal GQA (LM prefill, L5).  head_dim = 128, bf16 in/out, fp32
 // softmax and accumulation.  MFMA-bound: 4*n^2*128 flops per (sequence, head).
 //
-// One workgroup = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 rows.
+// One workgroup = 8 waves = 256 query rows of one (sequence, head) (or 4 waves = 128 rows); each wave owns 32 rows.
 // Everything is computed TRANSPOSED so that all per-row softmax state is lane-local:
 //     S^T[key][q] = K . Q^T      A = K tile (LDS),   B = Q   (registers, loaded once)
 //     O^T[d][q]   = V^T . P^T    A = V^T tile (LDS), B = P^T (registers, straight from S^T)
@@ -30,8 +30,8 @@ constexpr int VT_BYTES = 128 * 128;   // V^T tile
 constexpr int BUF_BYTES = KT_BYTES + VT_BYTES;
 constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64; THR = 0 reproduces the textbook rescale-every-tile
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(
+template <bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
     bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
     float scale_log2e) {
@@ -59,30 +59,31 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
     const bf16_t* Vbase = VT + (size_t)hkv * 128 * Tpad + qb.pad0;
 
     int n_tiles = (n + 63) >> 6;
-    if (CAUSAL) n_tiles = min(n_tiles, ((qb.q0 + 127) >> 6) + 1);
+    if (CAUSAL) n_tiles = min(n_tiles, ((qb.q0 + NW * 32 - 1) >> 6) + 1);
 
     // ---- staging (registers): 4 K chunks + 4 V^T chunks of 16 B per thread.  V lags K by one tile (see the loop). ----
-    u32x4 kst[4], vst[4];
+    constexpr int NT = NW * 64, IT = 1024 / NT;        // 16-B chunks per thread per tile
+    u32x4 kst[IT], vst[IT];
     auto load_k = [&](int j) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid;
+        for (int it = 0; it < IT; ++it) {
+            const int item = it * NT + tid;
             const int row = min(j * 64 + (item >> 4), n - 1);
             kst[it] = *reinterpret_cast<const u32x4*>(Kbase + (size_t)row * 128 + (item & 15) * 8);
         }
     };
     auto load_v = [&](int j) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid;
+        for (int it = 0; it < IT; ++it) {
+            const int item = it * NT + tid;
             vst[it] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)(item >> 3) * Tpad + j * 64 + (item & 7) * 8);
         }
     };
     auto write_k = [&](int buf) {
         char* kb = smem + buf * BUF_BYTES;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid;
+        for (int it = 0; it < IT; ++it) {
+            const int item = it * NT + tid;
             const int row = item >> 4, c = item & 15;
             *reinterpret_cast<u32x4*>(kb + row * 256 + ((c ^ (row & 15)) << 4)) = kst[it];
         }
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
     auto write_v = [&](int buf) {
         char* vb = smem + buf * BUF_BYTES + KT_BYTES;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = it * 256 + tid;
+        for (int it = 0; it < IT; ++it) {
+            const int item = it * NT + tid;
             const int d = item >> 3, cv = item & 7;
             *reinterpret_cast<u32x4*>(vb + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4)) = vst[it];
         }
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(
         // ---- mask (only the ragged last tile / the causal diagonal) ----
         const int key0 = j * 64;
         bool need_mask = (key0 + 64 > n);
-        if (CAUSAL) need_mask = need_mask || (key0 + 63 > qb.q0);
+        if (CAUSAL) need_mask = need_mask || (key0 + 63 > qb.q0);      // the block's first row decides
         if (need_mask) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -238,10 +239,24 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
     if (n_blocks <= 0) return hipSuccess;
     if (Hq % Hkv != 0) return hipErrorInvalidValue;
     const float c = scale * 1.44269504088896340736f;
-    dim3 grid(n_blocks), block(256);         // n_blocks = work items (seq x head x query block)
-    if (causal)
-        hipLaunchKernelGGL(flash_attn_kernel<true>, grid, block, 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
-    else
-        hipLaunchKernelGGL(flash_attn_kernel<false>, grid, block, 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+    dim3 grid(n_blocks);                      // n_blocks = work items (seq x head x query block)
+    if (flash_rows_per_block() == 256) {
+        if (causal)
+            hipLaunchKernelGGL((flash_attn_kernel<true, 8>), grid, dim3(512), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+        else
+            hipLaunchKernelGGL((flash_attn_kernel<false, 8>), grid, dim3(512), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+    } else {
+        if (causal)
+            hipLaunchKernelGGL((flash_attn_kernel<true, 4>), grid, dim3(256), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+        else
+            hipLaunchKernelGGL((flash_attn_kernel<false, 4>), grid, dim3(256), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+    }
     return hipGetLastError();
+}
+
+// query rows per work item: 256 (8 waves sharing each K/V tile, 1 workgroup per CU; default: half the global->LDS staging
+// work per wave, measured +2-3 % in interleaved A/B) or 128 (4 waves, 2 independent workgroups per CU; DOTS_OCR_ATTN_ROWS128=1)
+int flash_rows_per_block() {
+    static const int rows = getenv("DOTS_OCR_ATTN_ROWS128") ? 128 : 256;
+    return rows;
 }

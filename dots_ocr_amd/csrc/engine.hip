@@ -437,7 +437,7 @@ void build_worklists(const std::vector<int>& lens, int Hq, std::vector<Tile64>& 
         const int n = lens[s];
         for (int t = 0; t * 64 < n; ++t) tiles.push_back(Tile64{tok0 + t * 64, std::min(64, n - t * 64), pad0 + t * 64, (int)s, t, 0});
         for (int h = 0; h < Hq; ++h)
-            for (int q = 0; q < n; q += 128) qblocks.push_back(QBlock{q, n, tok0, pad0, h, 0});
+            for (int q = 0; q < n; q += flash_rows_per_block()) qblocks.push_back(QBlock{q, n, tok0, pad0, h, 0});
         tok0 += n;
         pad0 += (int)round_up(n, 64);
     }

@@ -33,6 +33,7 @@ hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* row
 // One work item = (sequence, head, 128-row query block); the list is ordered seq-major, then head, then block, so that
 // the XCD-contiguous remap of the 1-D grid gives one XCD (one L2) all query blocks that stream the same K/V.
 struct QBlock { int32_t q0, n, tok0, pad0, head, _pad; };   // first row in seq, seq length, packed token offset, padded V^T offset
+int flash_rows_per_block();      // 128 or 256 query rows per QBlock work item (what build_worklists must use)
 hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                              const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
                              int causal, float scale);
