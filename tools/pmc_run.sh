@@ -2,7 +2,5 @@
 # a silent crash followed by a hung profiler once cost 15 GPU-minutes.
 cd /tmp && export TMPDIR=/tmp; ulimit -c 0
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
-timeout 300 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -3
-timeout 200 python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/bench.out 2> $R/gpurun_out/bench.err; echo rc=$?
-python -c "
-import json; d=json.load(open('$R/gpurun_out/bench.out')); print(d['value'], d['phase_ms_per_step'], d['roofline']['achieved'], d['roofline_vit']['achieved'], d['roofline_decode']['ms_per_decode_step'])"; grep -v amdgpu.ids $R/gpurun_out/bench.err | tail -3
+timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f3 -- python $R/bench.py --steps 1 --warmup 0 --max-new-tokens 2 --no-cpu-baseline > $R/gpurun_out/pmc_fetch3.log 2>&1; echo rc=$?
+timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w3 -- python $R/bench.py --steps 1 --warmup 0 --max-new-tokens 2 --no-cpu-baseline > $R/gpurun_out/pmc_write3.log 2>&1; echo rc=$?
