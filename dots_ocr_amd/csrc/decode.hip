@@ -286,6 +286,24 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
 // greedy step glue: argmax (first index wins ties, like torch.argmax) in two stages, then EOS / length bookkeeping.
 constexpr int ARGMAX_CHUNKS = 64;
 
+// Commit one selected token of row (slot) b: append to its output, EOS / length bookkeeping, next-step input.
+// A finished row keeps decoding (fixed-shape graph) but its context is frozen, so it rewrites the same KV position for ever
+// and can idle in its slot until the host refills it (continuous batching).
+DEVI void commit_token(const StepState& st, int b, int tok) {
+    const bool done = st.finished[b] != 0;
+    if (st.advance_ctx && !done) st.ctx_len[b] += 1;
+    if (!done) {
+        const int n = st.out_lens[b];
+        const int cap = st.max_len ? st.max_len[b] : st.cap;
+        st.out_ids[(size_t)b * st.out_stride + n] = tok;
+        st.out_lens[b] = n + 1;
+        bool eos = false;
+        for (int k = 0; k < st.n_eos; ++k) eos = eos || (tok == st.eos_ids[k]);
+        if (eos || n + 1 >= cap) st.finished[b] = 1;
+    }
+    st.cur_tokens[b] = tok;
+}
+
 DEVI void argmax_merge(float& best, int& bi, float ov, int oi) {
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
 }
@@ -314,28 +332,14 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 }
 
 // grid B, one wave: final merge + bookkeeping
-__global__ __launch_bounds__(64) void argmax_step_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
-                                                         int32_t* __restrict__ cur_tokens, int32_t* __restrict__ ctx_len,
-                                                         int32_t* __restrict__ out_ids, int32_t* __restrict__ out_lens,
-                                                         int32_t* __restrict__ finished, const int32_t* __restrict__ eos_ids, int n_eos,
-                                                         int max_new_tokens, int advance_ctx) {
+__global__ __launch_bounds__(64) void argmax_step_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, StepState st) {
     const int b = blockIdx.x;
+    if (st.sel && !st.sel[b]) return;
     float best = pval[b * ARGMAX_CHUNKS + threadIdx.x];
     int bi = pidx[b * ARGMAX_CHUNKS + threadIdx.x];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) argmax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
-    if (threadIdx.x == 0) {
-        if (advance_ctx) ctx_len[b] += 1;
-        if (!finished[b]) {
-            const int n = out_lens[b];
-            out_ids[(size_t)b * max_new_tokens + n] = bi;
-            out_lens[b] = n + 1;
-            bool eos = false;
-            for (int k = 0; k < n_eos; ++k) eos = eos || (bi == eos_ids[k]);
-            if (eos || n + 1 >= max_new_tokens) finished[b] = 1;
-        }
-        cur_tokens[b] = bi;
-    }
+    if (threadIdx.x == 0) commit_token(st, b, bi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,14 +378,11 @@ DEVI uint64_t splitmix64(uint64_t x) {
 }
 
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float* __restrict__ logits, int V, int ld, float inv_temp,
-                                                                     float top_p, uint64_t seed, int32_t* __restrict__ cur_tokens,
-                                                                     int32_t* __restrict__ ctx_len, int32_t* __restrict__ out_ids,
-                                                                     int32_t* __restrict__ out_lens, int32_t* __restrict__ finished,
-                                                                     const int32_t* __restrict__ eos_ids, int n_eos, int max_new_tokens,
-                                                                     int advance_ctx) {
+                                                                     float top_p, uint64_t seed, StepState st) {
     __shared__ float red[SAMPLE_THREADS / 64];
     __shared__ float scan[SAMPLE_THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (st.sel && !st.sel[b]) return;                                // uniform per workgroup
     const float* row = logits + (size_t)b * ld;
     const int C = (V + SAMPLE_THREADS - 1) / SAMPLE_THREADS;         // contiguous chunk per thread: index order is preserved
     const int lo = tid * C, hi = min(V, lo + C);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float
     scan[tid] = part;
     __syncthreads();
     if (tid == 0) {                                                   // serial scan of 1024 partials: ~1 us, once per step
-        const int pos = out_lens[b];
+        const int pos = st.out_lens[b];
         const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)b << 32) | (uint32_t)pos));
         const float u = (float)(h >> 40) * (1.0f / 16777216.0f);     // [0, 1)
         float total = 0.f;
@@ -428,16 +429,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float
             float best = -INFINITY;
             for (int i = 0; i < V; ++i) if (row[i] > best) { best = row[i]; tok = i; }
         }
-        if (advance_ctx) ctx_len[b] += 1;
-        if (!finished[b]) {
-            const int n = out_lens[b];
-            out_ids[(size_t)b * max_new_tokens + n] = tok;
-            out_lens[b] = n + 1;
-            bool eos = false;
-            for (int k = 0; k < n_eos; ++k) eos = eos || (tok == eos_ids[k]);
-            if (eos || n + 1 >= max_new_tokens) finished[b] = 1;
-        }
-        cur_tokens[b] = tok;
+        commit_token(st, b, tok);
     }
 }
 
@@ -484,20 +476,15 @@ hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const 
     return hipGetLastError();
 }
 
-hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx,
-                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
-                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx) {
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx, const StepState& st) {
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_CHUNKS, B), dim3(256), 0, s, logits, V, ld, pval, pidx);
-    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, cur_tokens, ctx_len, out_ids, out_lens,
-                       finished, eos_ids, n_eos, max_new_tokens, advance_ctx);
+    hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, pval, pidx, st);
     return hipGetLastError();
 }
 
 hipError_t launch_sample_step(hipStream_t s, const float* logits, int V, int ld, int B, float temperature, float top_p, uint64_t seed,
-                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
-                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx) {
+                              const StepState& st) {
     if (temperature <= 0.f || top_p <= 0.f) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(SAMPLE_THREADS), 0, s, logits, V, ld, 1.0f / temperature, fminf(top_p, 1.0f), seed,
-                       cur_tokens, ctx_len, out_ids, out_lens, finished, eos_ids, n_eos, max_new_tokens, advance_ctx);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(SAMPLE_THREADS), 0, s, logits, V, ld, 1.0f / temperature, fminf(top_p, 1.0f), seed, st);
     return hipGetLastError();
 }

@@ -195,13 +195,13 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ rows,
-                                                          bf16_t* __restrict__ y, int n, int dim) {
+                                                          const int32_t* __restrict__ dst, bf16_t* __restrict__ y, int n, int dim) {
     const int l = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     const bf16_t* s = x + (size_t)rows[r] * dim;
-    for (int off = l * 8; off < dim; off += 512)
-        *reinterpret_cast<u32x4*>(y + (size_t)r * dim + off) = *reinterpret_cast<const u32x4*>(s + off);
+    bf16_t* d = y + (size_t)(dst ? dst[r] : r) * dim;
+    for (int off = l * 8; off < dim; off += 512) *reinterpret_cast<u32x4*>(d + off) = *reinterpret_cast<const u32x4*>(s + off);
 }
 
 }  // namespace
@@ -249,8 +249,8 @@ hipError_t launch_embed_gather(hipStream_t s, const int32_t* src, const bf16_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, bf16_t* y, int n, int dim) {
+hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, const int32_t* dst, bf16_t* y, int n, int dim) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, rows, y, n, dim);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, rows, dst, y, n, dim);
     return hipGetLastError();
 }

@@ -145,6 +145,16 @@ struct DotsEngine {
     float *d_slabs = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     int B = 0;                             // sequences of the current batch
     int B_sel = 0;                         // rows the token-selection kernel runs over
+    // ---- continuous batching: every sequence slot b < max_batch is free or occupied; the decode graph runs over rows
+    // [0, highest occupied slot] and only commits tokens for occupied, unfinished slots
+    bool slot_mode = false;
+    bool sel_dirty = true;
+    int slot_active[16] = {0};
+    int slot_limit[16] = {0};              // prompt length + generation cap of the slot's sequence
+    int32_t *d_sel = nullptr, *d_sel_new = nullptr, *d_max_len = nullptr, *p_dst = nullptr;
+    const int32_t* sel_now = nullptr;      // selection mask of the next select_tokens() call
+    struct StepGraph { int rows, splits; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<StepGraph> step_graphs;
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
 
@@ -407,6 +417,10 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->out_lens, (size_t)mb));
     CK(e->alloc(&e->finished, (size_t)mb));
     CK(e->alloc(&e->eos_ids, (size_t)16));
+    CK(e->alloc(&e->d_sel, (size_t)16));
+    CK(e->alloc(&e->d_sel_new, (size_t)16));
+    CK(e->alloc(&e->d_max_len, (size_t)16));
+    CK(e->alloc(&e->p_dst, (size_t)16));
     CK(e->alloc(&e->am_idx, (size_t)mb * 64));
     CK(e->alloc(&e->am_val, (size_t)mb * 64));
     CK(e->alloc(&e->d_h, (size_t)16 * H));
@@ -429,13 +443,16 @@ int alloc_workspaces(DotsEngine* e) {
 }
 
 // sequences -> 64-token tiles and 128-row query blocks
-void build_worklists(const std::vector<int>& lens, int Hq, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used) {
+// (Tile64.seq = the KV slot of the sequence: seq_ids[s], or s itself)
+void build_worklists(const std::vector<int>& lens, int Hq, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used,
+                     const int* seq_ids = nullptr) {
     tiles.clear();
     qblocks.clear();
     int tok0 = 0, pad0 = 0;
     for (size_t s = 0; s < lens.size(); ++s) {
         const int n = lens[s];
-        for (int t = 0; t * 64 < n; ++t) tiles.push_back(Tile64{tok0 + t * 64, std::min(64, n - t * 64), pad0 + t * 64, (int)s, t, 0});
+        const int seq = seq_ids ? seq_ids[s] : (int)s;
+        for (int t = 0; t * 64 < n; ++t) tiles.push_back(Tile64{tok0 + t * 64, std::min(64, n - t * 64), pad0 + t * 64, seq, t, 0});
         for (int h = 0; h < Hq; ++h)
             for (int q = 0; q < n; q += flash_rows_per_block()) qblocks.push_back(QBlock{q, n, tok0, pad0, h, 0});
         tok0 += n;
@@ -537,27 +554,51 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
 // greedy arg max or temperature / top-p sampling over the fp32 logits of the step
 int select_tokens(DotsEngine* e, int advance) {
     const DotsConfig& c = e->cfg;
-    if (e->temperature > 0.f) {
-        CK(launch_sample_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->temperature, e->top_p, e->seed, e->cur_tokens,
-                              e->ctx_len, e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, advance));
-    } else {
-        CK(launch_argmax_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->am_val, e->am_idx, e->cur_tokens, e->ctx_len,
-                              e->out_ids, e->out_lens, e->finished, e->eos_ids, e->n_eos, e->out_cap, advance));
-    }
+    StepState st;
+    st.cur_tokens = e->cur_tokens; st.ctx_len = e->ctx_len; st.out_ids = e->out_ids; st.out_lens = e->out_lens; st.finished = e->finished;
+    st.eos_ids = e->eos_ids; st.n_eos = e->n_eos; st.advance_ctx = advance;
+    if (e->slot_mode) { st.sel = e->sel_now; st.max_len = e->d_max_len; st.out_stride = c.max_seq_len; st.cap = c.max_seq_len; }
+    else { st.sel = nullptr; st.max_len = nullptr; st.out_stride = e->out_cap; st.cap = e->out_cap; }
+    if (e->temperature > 0.f)
+        CK(launch_sample_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->temperature, e->top_p, e->seed, st));
+    else
+        CK(launch_argmax_step(e->stream, e->d_logits, c.vocab_size, c.vocab_size, e->B_sel, e->am_val, e->am_idx, st));
     return DOTS_OK;
 }
 
-int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
+void drop_step_graphs(DotsEngine* e) {
+    for (auto& g : e->step_graphs) {
+        hipGraphExecDestroy(g.exec);
+        hipGraphDestroy(g.graph);
+    }
+    e->step_graphs.clear();
+}
+
+// Prefill B packed prompts.  slots == nullptr: the static batch (sequence b -> slot b, every slot reset).
+// slots != nullptr: continuous batching, sequence b goes into the free slot slots[b] with its own generation cap;
+// the other slots' KV pages, contexts and outputs are not touched.
+int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const int32_t* slots = nullptr, const int32_t* max_new = nullptr) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
     const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, Nkv = Hkv * 128, NQKV = Nq + 2 * Nkv;
     if (B < 1 || B > c.max_batch || B > 16) return e->fail(DOTS_E_CAPACITY, "batch %d exceeds max_batch %d (<= 16)", B, c.max_batch);
     int64_t T = 0;
-    std::vector<int> L(B);
+    std::vector<int> L(B), S(B);
+    int rows = B;                                           // rows of the last-position / lm_head / selection stage
     for (int b = 0; b < B; ++b) {
         if (lens[b] < 1 || lens[b] >= c.max_seq_len) return e->fail(DOTS_E_CAPACITY, "prompt %d length %d not in [1, max_seq_len)", b, lens[b]);
         L[b] = lens[b];
         T += lens[b];
+        S[b] = slots ? slots[b] : b;
+        if (slots) {
+            if (S[b] < 0 || S[b] >= c.max_batch) return e->fail(DOTS_E_INVALID, "slot %d out of range [0, %d)", S[b], c.max_batch);
+            if (e->slot_mode && e->slot_active[S[b]]) return e->fail(DOTS_E_STATE, "slot %d is occupied", S[b]);
+            for (int a = 0; a < b; ++a)
+                if (S[a] == S[b]) return e->fail(DOTS_E_INVALID, "slot %d listed twice", S[b]);
+            if (max_new[b] < 1 || lens[b] + max_new[b] > c.max_seq_len)
+                return e->fail(DOTS_E_CAPACITY, "slot %d: prompt (%d) + max_new_tokens (%d) exceeds max_seq_len %d", S[b], lens[b], max_new[b], c.max_seq_len);
+            rows = std::max(rows, S[b] + 1);
+        }
     }
     if (T > e->TP) return e->fail(DOTS_E_CAPACITY, "packed prompt tokens %lld > max_prefill_tokens %lld", (long long)T, (long long)e->TP);
     e->hp_pos.resize(T); e->hp_src.resize(T); e->hp_last.assign(16, 0);
@@ -575,15 +616,36 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
     if (vis_used != (vis_used ? e->vis_rows : 0))
         return e->fail(DOTS_E_STATE, "prompt has %lld image tokens but the vision tower produced %lld rows", (long long)vis_used, (long long)e->vis_rows);
     int64_t Tpad = 0;
-    build_worklists(L, Hq, e->hp_tiles, e->hp_qblocks, &Tpad);
+    build_worklists(L, Hq, e->hp_tiles, e->hp_qblocks, &Tpad, S.data());
     CK(hipMemcpyAsync(e->p_pos, e->hp_pos.data(), T * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_src, e->hp_src.data(), T * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), 16 * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_tiles, e->hp_tiles.data(), e->hp_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_qblocks, e->hp_qblocks.data(), e->hp_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
-    CK(hipMemcpyAsync(e->ctx_len, lens, B * 4, hipMemcpyHostToDevice, s));
-    CK(hipMemsetAsync(e->out_lens, 0, 16 * 4, s));
-    CK(hipMemsetAsync(e->finished, 0, 16 * 4, s));
+    if (!slots) {
+        if (e->slot_mode) drop_step_graphs(e);
+        e->slot_mode = false;
+        std::fill(e->slot_active, e->slot_active + 16, 0);
+        CK(hipMemcpyAsync(e->ctx_len, lens, B * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemsetAsync(e->out_lens, 0, 16 * 4, s));
+        CK(hipMemsetAsync(e->finished, 0, 16 * 4, s));
+    } else {
+        if (!e->slot_mode) {                               // entering slot mode: every slot starts free
+            std::fill(e->slot_active, e->slot_active + 16, 0);
+            CK(hipMemsetAsync(e->ctx_len, 0, 16 * 4, s));
+            e->slot_mode = true;
+        }
+        int32_t sel_new[16] = {0};
+        for (int b = 0; b < B; ++b) {
+            sel_new[S[b]] = 1;
+            CK(hipMemcpyAsync(e->ctx_len + S[b], lens + b, 4, hipMemcpyHostToDevice, s));
+            CK(hipMemcpyAsync(e->d_max_len + S[b], max_new + b, 4, hipMemcpyHostToDevice, s));
+            CK(hipMemsetAsync(e->out_lens + S[b], 0, 4, s));
+            CK(hipMemsetAsync(e->finished + S[b], 0, 4, s));
+        }
+        CK(hipMemcpyAsync(e->d_sel_new, sel_new, 16 * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(e->p_dst, S.data(), B * 4, hipMemcpyHostToDevice, s));
+    }
 
     CK(hipEventRecord(e->ev[2], s));
     CK(launch_embed_gather(s, e->p_src, e->embed, e->vis, e->p_x, T, H));
@@ -604,13 +666,23 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B) {
         CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL));
     }
     // last position of every sequence -> final norm -> lm_head -> first token
-    CK(launch_gather_rows(s, e->p_x, e->p_last, e->d_h, B, H));
-    CK(launch_dec_lmhead(s, e->d_h, nullptr, 0, nullptr, e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
-    e->B_sel = B;
+    CK(launch_gather_rows(s, e->p_x, e->p_last, slots ? e->p_dst : nullptr, e->d_h, B, H));
+    CK(launch_dec_lmhead(s, e->d_h, nullptr, 0, nullptr, e->final_norm, e->lm_head_d, e->d_logits, rows, H, c.vocab_size, c.rms_norm_eps));
+    e->B_sel = rows;
+    e->sel_now = e->d_sel_new;
     RET(select_tokens(e, 0));
     CK(hipEventRecord(e->ev[3], s));
-    e->B = B;
-    e->h_prompt_lens = L;
+    if (slots) {
+        for (int b = 0; b < B; ++b) {
+            e->slot_active[S[b]] = 1;
+            e->slot_limit[S[b]] = L[b] + max_new[b];
+        }
+        e->sel_dirty = true;
+        e->B = 0;                                          // the static-batch entry points need a static prefill first
+    } else {
+        e->B = B;
+        e->h_prompt_lens = L;
+    }
     e->steps_done = 0;
     e->vis_rows = 0;
     e->stats.prefill_tokens = T;
@@ -650,6 +722,7 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
     }
     CK(launch_dec_lmhead(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = B;
+    e->sel_now = e->d_sel;
     RET(select_tokens(e, 1));
     return DOTS_OK;
 }
@@ -705,6 +778,7 @@ void dots_destroy(DotsEngine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    drop_step_graphs(e);
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->attn_ev) hipEventDestroy(ev);
@@ -857,6 +931,114 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     return DOTS_OK;
 }
 
+// ---------------------------------------------------------------------------------- continuous batching
+int dots_set_eos(DotsEngine* e, const int32_t* eos_ids, int n_eos) {
+    if (!e) return DOTS_E_INVALID;
+    if (n_eos < 0 || n_eos > 16 || (n_eos && !eos_ids)) return e->fail(DOTS_E_INVALID, "n_eos must be in [0,16]");
+    CK(hipSetDevice(e->device));
+    if (n_eos) CK(hipMemcpyAsync(e->eos_ids, eos_ids, n_eos * 4, hipMemcpyHostToDevice, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    if (n_eos != e->n_eos) drop_step_graphs(e);
+    e->n_eos = n_eos;
+    return DOTS_OK;
+}
+
+int dots_slots_prefill(DotsEngine* e, const int32_t* slots, int n, const int32_t* input_ids, const int32_t* prompt_lens,
+                       const int32_t* max_new_tokens) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    if (!slots || !input_ids || !prompt_lens || !max_new_tokens) return e->fail(DOTS_E_INVALID, "null argument");
+    CK(hipSetDevice(e->device));
+    return prefill(e, input_ids, prompt_lens, n, slots, max_new_tokens);
+}
+
+int dots_slots_decode(DotsEngine* e, int n_steps) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->slot_mode) return e->fail(DOTS_E_STATE, "no slot has been prefilled");
+    if (n_steps < 1) return e->fail(DOTS_E_INVALID, "n_steps must be >= 1");
+    CK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    int rows = 0, limit = 0;
+    for (int b = 0; b < e->cfg.max_batch; ++b)
+        if (e->slot_active[b]) {
+            rows = b + 1;
+            limit = std::max(limit, e->slot_limit[b]);
+        }
+    if (!rows) return e->fail(DOTS_E_STATE, "every slot is free");
+    if (e->sel_dirty) {
+        int32_t sel[16];
+        for (int b = 0; b < 16; ++b) sel[b] = e->slot_active[b];
+        CK(hipMemcpyAsync(e->d_sel, sel, 16 * 4, hipMemcpyHostToDevice, s));
+        e->sel_dirty = false;
+    }
+    const int n_splits = splits_for_ctx(limit);
+    e->B = rows;
+    static const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        for (auto& g : e->step_graphs)
+            if (g.rows == rows && g.splits == n_splits) exec = g.exec;
+        if (!exec) {
+            if (e->step_graphs.size() >= 32) drop_step_graphs(e);
+            DotsEngine::StepGraph g{rows, n_splits, nullptr, nullptr};
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int r = decode_step_launches(e, n_splits);
+            hipError_t ce = hipStreamEndCapture(s, &g.graph);
+            if (r != DOTS_OK) { e->B = 0; return r; }
+            CK(ce);
+            CK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            e->step_graphs.push_back(g);
+            exec = g.exec;
+        }
+    }
+    int r = DOTS_OK;
+    for (int i = 0; i < n_steps && r == DOTS_OK; ++i) {
+        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) r = e->fail(DOTS_E_HIP, "hipGraphLaunch failed"); }
+        else r = decode_step_launches(e, n_splits);
+    }
+    e->B = 0;
+    e->stats.decode_steps += n_steps;
+    return r;
+}
+
+int dots_slots_poll(DotsEngine* e, int32_t* finished, int32_t* out_lens) {
+    if (!e || !finished || !out_lens) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    const int mb = e->cfg.max_batch;
+    CK(hipMemcpyAsync(finished, e->finished, mb * 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipMemcpyAsync(out_lens, e->out_lens, mb * 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < mb; ++b)
+        if (!e->slot_mode || !e->slot_active[b]) { finished[b] = -1; out_lens[b] = 0; }      // -1: free slot
+    return DOTS_OK;
+}
+
+int dots_slot_read(DotsEngine* e, int slot, int32_t* out_ids, int capacity, int32_t* n_out) {
+    if (!e || !out_ids || !n_out || capacity < 0) return e ? e->fail(DOTS_E_INVALID, "bad slot_read arguments") : DOTS_E_INVALID;
+    if (!e->slot_mode || slot < 0 || slot >= e->cfg.max_batch || !e->slot_active[slot]) return e->fail(DOTS_E_STATE, "slot %d is not occupied", slot);
+    CK(hipSetDevice(e->device));
+    int32_t n = 0;
+    CK(hipMemcpyAsync(&n, e->out_lens + slot, 4, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    *n_out = n;
+    const int take = std::min<int>(n, capacity);
+    if (take > 0) {
+        CK(hipMemcpyAsync(out_ids, e->out_ids + (size_t)slot * e->cfg.max_seq_len, (size_t)take * 4, hipMemcpyDeviceToHost, e->stream));
+        CK(hipStreamSynchronize(e->stream));
+    }
+    return DOTS_OK;
+}
+
+int dots_slot_release(DotsEngine* e, int slot) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->slot_mode || slot < 0 || slot >= e->cfg.max_batch || !e->slot_active[slot]) return e->fail(DOTS_E_STATE, "slot %d is not occupied", slot);
+    CK(hipSetDevice(e->device));
+    e->slot_active[slot] = 0;
+    e->sel_dirty = true;
+    CK(hipMemsetAsync(e->ctx_len + slot, 0, 4, e->stream));          // an idle row attends over one key only
+    return DOTS_OK;
+}
+
 int dots_get_stats(DotsEngine* e, DotsStats* out) {
     if (!e || !out) return DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
@@ -936,6 +1118,7 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
     e->temperature = temperature;
     e->top_p = top_p > 1.f ? 1.f : top_p;
     e->seed = seed;
+    drop_step_graphs(e);                                   // the captured decode steps bake these values in
     return DOTS_OK;
 }
 

@@ -27,7 +27,8 @@ hipError_t launch_qkv_rope_split(hipStream_t s, const bf16_t* qkv, const float2*
 // x[t] = src[t] >= 0 ? embed[src[t]] : vision[-src[t]-1]
 hipError_t launch_embed_gather(hipStream_t s, const int32_t* src, const bf16_t* embed, const bf16_t* vision, bf16_t* x,
                                int64_t T, int dim);
-hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, bf16_t* y, int n, int dim);
+// y[dst ? dst[r] : r] = x[rows[r]]
+hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* rows, const int32_t* dst, bf16_t* y, int n, int dim);
 
 // ---- attn_prefill.hip
 // One work item = (sequence, head, 128-row query block); the list is ordered seq-major, then head, then block, so that
@@ -60,12 +61,17 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
                               int B, int Hq, int Hkv, int n_splits, float scale);
 hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits);
-hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx,
-                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
-                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx);
+// Per-step token bookkeeping state (device pointers), shared by the arg-max and the sampling kernels.
+//   sel     rows (slots) to act on this call, or nullptr = all B rows
+//   max_len per-row cap on generated tokens, or nullptr = `cap` for every row
+struct StepState {
+    int32_t *cur_tokens, *ctx_len, *out_ids, *out_lens, *finished;
+    const int32_t *eos_ids, *sel, *max_len;
+    int n_eos, out_stride, cap, advance_ctx;
+};
+hipError_t launch_argmax_step(hipStream_t s, const float* logits, int V, int ld, int B, float* pval, int32_t* pidx, const StepState& st);
 hipError_t launch_sample_step(hipStream_t s, const float* logits, int V, int ld, int B, float temperature, float top_p, uint64_t seed,
-                              int32_t* cur_tokens, int32_t* ctx_len, int32_t* out_ids, int32_t* out_lens, int32_t* finished,
-                              const int32_t* eos_ids, int n_eos, int max_new_tokens, int advance_ctx);
+                              const StepState& st);
 // row-major [rows, K] -> MFMA fragment order (decode.hip): 16-row tiles x K/32 chunks of 1 KiB
 hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K);
 // ---- engine.hip helper kernels

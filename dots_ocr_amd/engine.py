@@ -69,6 +69,12 @@ def _prototypes(lib):
         "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
         "dots_preprocess_image": (i32, [vp, vp, i32, i32, i32, i32, i32, P(i32), P(i32), i32, P(i32), P(i32), i32, P(f32), P(f32), f32, vp]),
         "dots_set_sampling": (i32, [vp, f32, f32, C.c_uint64]),
+        "dots_set_eos": (i32, [vp, P(i32), i32]),
+        "dots_slots_prefill": (i32, [vp, P(i32), i32, P(i32), P(i32), P(i32)]),
+        "dots_slots_decode": (i32, [vp, i32]),
+        "dots_slots_poll": (i32, [vp, P(i32), P(i32)]),
+        "dots_slot_read": (i32, [vp, i32, P(i32), i32, P(i32)]),
+        "dots_slot_release": (i32, [vp, i32]),
         "dots_get_logits": (i32, [vp, P(f32)]),
         "dots_set_next_tokens": (i32, [vp, P(i32), i32]),
         "dots_get_last_tokens": (i32, [vp, P(i32)]),
@@ -96,6 +102,7 @@ def _prototypes(lib):
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
     "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_get_logits",
+    "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma",
@@ -139,6 +146,7 @@ class Engine:
         self.max_patches = max_patches
         if max_prefill_tokens is None:
             max_prefill_tokens = max_batch * max_seq_len
+        self.max_prefill_tokens = max_prefill_tokens
         self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens)
         h = C.c_void_p()
         rc = self.lib.dots_create(C.byref(self._cc), device, C.byref(h))
@@ -256,6 +264,38 @@ class Engine:
 
     def decode_step(self):
         self._ck(self.lib.dots_decode_step(self.h), "dots_decode_step")
+
+    # ------------------------------------------------------------------ continuous batching (sequence slots)
+    def set_eos(self, eos_ids: Sequence[int]):
+        eos = np.ascontiguousarray(list(eos_ids), dtype=np.int32)
+        self._ck(self.lib.dots_set_eos(self.h, _i32p(eos) if len(eos) else None, len(eos)), "dots_set_eos")
+
+    def slots_prefill(self, slots: Sequence[int], input_ids: np.ndarray, prompt_lens: Sequence[int], max_new_tokens: Sequence[int]):
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        lens = np.ascontiguousarray(prompt_lens, dtype=np.int32)
+        cap = np.ascontiguousarray(max_new_tokens, dtype=np.int32)
+        assert sl.shape == lens.shape == cap.shape and ids.shape[0] == int(lens.sum())
+        self._ck(self.lib.dots_slots_prefill(self.h, _i32p(sl), sl.shape[0], _i32p(ids), _i32p(lens), _i32p(cap)), "dots_slots_prefill")
+
+    def slots_decode(self, n_steps: int):
+        self._ck(self.lib.dots_slots_decode(self.h, int(n_steps)), "dots_slots_decode")
+
+    def slots_poll(self):
+        """-> (finished [max_batch]: -1 free / 0 running / 1 finished, out_lens [max_batch])"""
+        fin = np.empty((self.max_batch,), dtype=np.int32)
+        lens = np.empty((self.max_batch,), dtype=np.int32)
+        self._ck(self.lib.dots_slots_poll(self.h, _i32p(fin), _i32p(lens)), "dots_slots_poll")
+        return fin, lens
+
+    def slot_read(self, slot: int, capacity: int) -> np.ndarray:
+        out = np.empty((max(1, capacity),), dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self.lib.dots_slot_read(self.h, int(slot), _i32p(out), int(capacity), C.byref(n)), "dots_slot_read")
+        return out[:min(int(n.value), capacity)].copy()
+
+    def slot_release(self, slot: int):
+        self._ck(self.lib.dots_slot_release(self.h, int(slot)), "dots_slot_release")
 
     def get_logits(self) -> np.ndarray:
         out = np.empty((self._B, self.cfg.vocab_size), dtype=np.float32)

@@ -1,0 +1,149 @@
+"""Continuous batching over the engine's sequence slots.
+
+The reference gets this from its vLLM server: ``DotsOCRParser`` fires one request per page from a thread pool
+(dots_ocr/parser.py:138-166, model/inference.py:8-50) and the server keeps its running batch full, admitting a new
+page whenever one finishes.  Here the same policy runs in-process on top of the C-ABI slot calls
+(include/dots_ocr_hip.h "Continuous batching"): FIFO admission into free slots within the ViT / prefill workspace
+budgets, fixed-size decode chunks replayed from a captured graph, finished sequences read out and their slots reused.
+
+A page's tokens do not depend on what shares the batch with it (every kernel on the path is row-independent), so the
+result of a request is the same as a single-sequence ``generate`` — tests/test_model_gpu.py checks exactly that.
+"""
+from __future__ import annotations
+
+from collections import deque
+from dataclasses import dataclass
+from typing import Deque, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Request:
+    input_ids: np.ndarray                       # int32 [T]; image pad tokens already expanded (processor output)
+    pixel_values: Optional[object] = None       # float32 [n_patches, patch_dim]: numpy array or torch CUDA tensor
+    grid_thw: Optional[np.ndarray] = None       # int64 [n_img, 3]
+    max_new_tokens: int = 128
+    tag: object = None
+
+    def n_patches(self) -> int:
+        if self.grid_thw is None:
+            return 0
+        g = np.asarray(self.grid_thw, dtype=np.int64).reshape(-1, 3)
+        return int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+
+
+class ContinuousBatcher:
+    """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
+
+    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16):
+        self.engine = engine
+        self.chunk = max(1, int(chunk))
+        self.n_slots = int(engine.max_batch)
+        self.max_patches = int(engine.max_patches)
+        self.max_prefill_tokens = int(engine.max_prefill_tokens)
+        self.max_seq_len = int(engine.max_seq_len)
+        self.pending: Deque[Tuple[int, Request]] = deque()
+        self.running: Dict[int, Tuple[int, Request]] = {}        # slot -> (request id, request)
+        self._next_id = 0
+        self.decode_steps = 0
+        self.admissions = 0
+        engine.set_eos(list(eos_ids))
+
+    # ------------------------------------------------------------------ queue
+    def submit(self, req: Request) -> int:
+        ids = np.ascontiguousarray(req.input_ids, dtype=np.int32).reshape(-1)
+        if ids.shape[0] < 1 or ids.shape[0] >= self.max_seq_len:
+            raise ValueError(f"prompt of {ids.shape[0]} tokens does not fit max_seq_len={self.max_seq_len}")
+        if ids.shape[0] > self.max_prefill_tokens:
+            raise ValueError(f"prompt of {ids.shape[0]} tokens exceeds max_prefill_tokens={self.max_prefill_tokens}")
+        if req.n_patches() > self.max_patches:
+            raise ValueError(f"request has {req.n_patches()} vision patches, more than max_patches={self.max_patches}")
+        req.input_ids = ids
+        # like HF generate, stop at the context capacity instead of failing
+        req.max_new_tokens = max(1, min(int(req.max_new_tokens), self.max_seq_len - ids.shape[0]))
+        rid = self._next_id
+        self._next_id += 1
+        self.pending.append((rid, req))
+        return rid
+
+    @property
+    def idle(self) -> bool:
+        return not self.pending and not self.running
+
+    def free_slots(self) -> List[int]:
+        return [s for s in range(self.n_slots) if s not in self.running]
+
+    # ------------------------------------------------------------------ admission
+    def plan_admission(self) -> List[Tuple[int, int, Request]]:
+        """FIFO: pop requests while a slot is free and the group fits the ViT and prefill workspaces.
+        Lowest slots first, so the decode graph covers as few rows as possible."""
+        free = self.free_slots()
+        group, patches, tokens = [], 0, 0
+        while self.pending and free:
+            rid, req = self.pending[0]
+            p, t = req.n_patches(), int(req.input_ids.shape[0])
+            if group and (patches + p > self.max_patches or tokens + t > self.max_prefill_tokens):
+                break
+            self.pending.popleft()
+            group.append((free.pop(0), rid, req))
+            patches += p
+            tokens += t
+        return group
+
+    def _admit(self, group):
+        with_img = [(s, rid, r) for s, rid, r in group if r.n_patches() > 0]
+        if with_img:
+            grid = np.concatenate([np.asarray(r.grid_thw, dtype=np.int64).reshape(-1, 3) for _, _, r in with_img])
+            pvs = [r.pixel_values for _, _, r in with_img]
+            if all(hasattr(p, "is_cuda") and p.is_cuda for p in pvs):
+                import torch
+                pv = pvs[0] if len(pvs) == 1 else torch.cat(pvs, dim=0)
+                pv = pv.contiguous().float()
+                torch.cuda.current_stream().synchronize()
+                self.engine.vit_forward(pv.data_ptr(), grid, on_device=True)
+                self.engine.synchronize()            # `pv` may be a temporary
+            else:
+                host = [p.detach().cpu().numpy() if hasattr(p, "detach") else np.asarray(p) for p in pvs]
+                self.engine.vit_forward(np.concatenate(host).astype(np.float32, copy=False), grid)
+        # image rows are consumed in packed order, so sequences with images keep their relative order: pack the group as is
+        slots = [s for s, _, _ in group]
+        lens = [int(r.input_ids.shape[0]) for _, _, r in group]
+        caps = [int(r.max_new_tokens) for _, _, r in group]
+        self.engine.slots_prefill(slots, np.concatenate([r.input_ids for _, _, r in group]), lens, caps)
+        for s, rid, r in group:
+            self.running[s] = (rid, r)
+        self.admissions += 1
+
+    # ------------------------------------------------------------------ main loop
+    def _collect(self) -> List[Tuple[int, Request, np.ndarray]]:
+        fin, lens = self.engine.slots_poll()
+        done = []
+        for s in sorted(self.running):
+            if fin[s] == 1:
+                rid, req = self.running.pop(s)
+                done.append((rid, req, self.engine.slot_read(s, int(lens[s]))))
+                self.engine.slot_release(s)
+        return done
+
+    def step(self) -> List[Tuple[int, Request, np.ndarray]]:
+        """Admit what fits, run one decode chunk, return the requests that finished: (id, request, new token ids)."""
+        group = self.plan_admission()
+        if group:
+            self._admit(group)
+            done = self._collect()                   # a 1-token cap or an immediate EOS finishes at prefill
+            if done:
+                return done
+        if not self.running:
+            return []
+        self.engine.slots_decode(self.chunk)
+        self.decode_steps += self.chunk
+        return self._collect()
+
+    def run(self, requests: Iterable[Request]) -> List[np.ndarray]:
+        ids = [self.submit(r) for r in requests]
+        out: Dict[int, np.ndarray] = {}
+        while not self.idle:
+            for rid, _, toks in self.step():
+                out[rid] = toks
+        return [out[i] for i in ids]

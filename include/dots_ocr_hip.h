@@ -129,6 +129,29 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, 
  * from `seed` (counter-based: seed, batch slot, position). */
 int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed);
 
+/* ---- Continuous batching (the serving loop the reference delegates to vLLM: README "vLLM inference", parser.py:138-166
+ * fires one request per page at it and the server keeps its batch full).  The engine's max_batch KV slots are
+ * independent sequences: a finished sequence is read out, its slot released and refilled by a new prefill while the other
+ * slots keep decoding.  Any static-batch call (dots_prefill / dots_generate) resets every slot.
+ *
+ * dots_set_eos       stop tokens for the slot calls.
+ * dots_slots_prefill n new sequences (packed ids, like dots_prefill) into the free slots `slots[i]`, each with its own
+ *                    cap on generated tokens; if the prompts hold image tokens, run dots_vit_forward for exactly these
+ *                    sequences first.  Selects each new sequence's first token.
+ * dots_slots_decode  n_steps decode steps over all occupied slots (one captured graph per (rows, kv-split) shape).
+ *                    Finished sequences idle in place: their context is frozen and nothing more is appended.
+ * dots_slots_poll    finished[b] = -1 free / 0 running / 1 finished, out_lens[b] = tokens generated so far; both
+ *                    int32 [max_batch].  Synchronises the stream.
+ * dots_slot_read     copies min(n, capacity) generated ids of one occupied slot, *n_out = n.
+ * dots_slot_release  marks the slot free. */
+int dots_set_eos(DotsEngine* e, const int32_t* eos_ids_host, int n_eos);
+int dots_slots_prefill(DotsEngine* e, const int32_t* slots_host, int n, const int32_t* input_ids_host,
+                       const int32_t* prompt_lens_host, const int32_t* max_new_tokens_host);
+int dots_slots_decode(DotsEngine* e, int n_steps);
+int dots_slots_poll(DotsEngine* e, int32_t* finished_host, int32_t* out_lens_host);
+int dots_slot_read(DotsEngine* e, int slot, int32_t* out_ids_host, int capacity, int32_t* n_out);
+int dots_slot_release(DotsEngine* e, int slot);
+
 /* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
 int dots_get_logits(DotsEngine* e, float* out_host);
 /* Teacher forcing for per-step logit comparisons: overwrite the token the next decode step feeds. */

@@ -228,3 +228,76 @@ def test_plan_batches_respects_sequence_and_patch_budgets():
     assert plan_batches([0, 0, 0], 8, 100) == [[0, 1, 2]]                           # text-only prompts
     with pytest.raises(ValueError):
         plan_batches([200], 8, 100)
+
+
+def test_continuous_batcher_admission_and_refill_with_a_fake_engine():
+    """Scheduler logic only (no GPU): FIFO admission within the patch / token budgets, lowest free slot first, refill on finish."""
+    import numpy as np
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+
+    class FakeEngine:
+        max_batch, max_patches, max_prefill_tokens, max_seq_len = 3, 100, 64, 128
+
+        def __init__(self):
+            self.slots = {}            # slot -> [prompt, cap, produced]
+            self.log = []
+
+        def set_eos(self, eos): self.eos = list(eos)
+        def synchronize(self): pass
+
+        def vit_forward(self, pv, grid, on_device=False):
+            self.log.append(("vit", int(np.asarray(grid)[:, 1:].prod(axis=1).sum()), len(pv)))
+
+        def slots_prefill(self, slots, ids, lens, caps):
+            assert sum(lens) == len(ids) <= self.max_prefill_tokens
+            off = 0
+            for s, n, c in zip(slots, lens, caps):
+                assert s not in self.slots
+                self.slots[s] = [ids[off:off + n].copy(), c, 1]
+                off += n
+            self.log.append(("prefill", tuple(slots)))
+
+        def slots_decode(self, n):
+            assert self.slots
+            for st in self.slots.values():
+                st[2] = min(st[1], st[2] + n)
+            self.log.append(("decode", n, tuple(sorted(self.slots))))
+
+        def slots_poll(self):
+            fin = np.full(3, -1, np.int32)
+            lens = np.zeros(3, np.int32)
+            for s, (_, cap, n) in self.slots.items():
+                fin[s], lens[s] = int(n >= cap), n
+            return fin, lens
+
+        def slot_read(self, s, capacity):
+            prompt, _, n = self.slots[s]
+            return (int(prompt[0]) + np.arange(n, dtype=np.int32))[:capacity]      # "tokens" identify the request
+
+        def slot_release(self, s): del self.slots[s]
+
+    eng = FakeEngine()
+    cb = ContinuousBatcher(eng, eos_ids=(7,), chunk=4)
+    assert eng.eos == [7]
+    def req(first, n_tok, cap, patches=0):
+        ids = np.full(n_tok, first, np.int32)
+        if patches:
+            return Request(ids, np.zeros((patches, 4), np.float32), np.array([[1, patches // 2, 2]]), cap)
+        return Request(ids, None, None, cap)
+    reqs = [req(10, 20, 9, 40), req(20, 20, 1, 40), req(30, 20, 6, 40),      # third does not fit the 100-patch ViT budget with the first two
+            req(40, 50, 3), req(50, 30, 200), req(60, 10, 5)]                # 50 + 30 tokens exceed the 64-token prefill budget
+    out = cb.run(reqs)
+    assert [o.tolist() for o in out] == [list(range(r.input_ids[0], r.input_ids[0] + min(r.max_new_tokens, 128 - len(r.input_ids))))
+                                         for r in reqs]
+    assert len(out[4]) == 98                                                 # cap clamped to the context capacity
+    pre = [e[1] for e in eng.log if e[0] == "prefill"]
+    assert pre[0] == (0, 1)                                                  # two pages fit the ViT budget
+    assert pre[1] == (1,)                                                    # request 1 finished at prefill: its slot is reused at once
+    assert all(len(p) <= 3 for p in pre) and sum(len(p) for p in pre) == 6
+    vit = [e for e in eng.log if e[0] == "vit"]
+    assert [v[1] for v in vit] == [80, 40] and [v[2] for v in vit] == [80, 40]
+    assert cb.idle and not eng.slots
+    with pytest.raises(ValueError):
+        cb.submit(req(1, 200, 4))                                            # longer than max_seq_len
+    with pytest.raises(ValueError):
+        cb.submit(req(1, 10, 4, 400))                                        # more patches than the ViT workspace

@@ -242,3 +242,75 @@ def test_sampling_matches_softmax_and_respects_nucleus(setup):
         eng.prefill(ids, lens)
         assert int(eng.get_last_tokens()[0]) in nucleus
     eng.set_sampling(0.0, 1.0, 0)
+
+
+def test_continuous_batching_equals_single_sequence_generate(setup):
+    """9 pages of different sizes / length caps / EOS through the engine's 4 slots (3 used): every request's tokens are the ones
+    a single-sequence generate gives, regardless of which neighbours it shared decode steps with or which slot it reused."""
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg, sd, eng = setup
+    grids = [(1, 4, 6), (1, 6, 6), (1, 4, 4), (1, 8, 4), (1, 4, 4), (1, 6, 4), (1, 4, 6), (1, 4, 8), (1, 6, 4)]
+    caps = [7, 33, 1, 20, 12, 40, 5, 18, 26]
+    reqs, singles = [], []
+    eos = None
+    for i, (g, cap) in enumerate(zip(grids, caps)):
+        pv, grid, seqs = _inputs(cfg, [g], 3 + i % 4, seed=100 + i)
+        ids = seqs[0].numpy().astype(np.int32)
+        if i == 8:
+            pv, grid, ids = None, None, ids[ids != cfg.image_token_id]           # a text-only request
+        reqs.append((ids, pv, grid, cap))
+    # pick an EOS id that request 1 emits mid-way, so EOS and length caps both occur
+    free, _ = eng.generate(reqs[1][0], np.array([len(reqs[1][0])], np.int32), reqs[1][1].numpy(), reqs[1][2].numpy(), max_new_tokens=33)
+    eos = (int(free[0, 9]),)
+    for ids, pv, grid, cap in reqs:
+        out, n = eng.generate(ids, np.array([len(ids)], np.int32), None if pv is None else pv.numpy(),
+                              None if grid is None else grid.numpy(), max_new_tokens=cap, eos_ids=eos)
+        singles.append(out[0, :n[0]].tolist())
+    assert len(singles[1]) <= 10 and any(len(s) == c for s, c in zip(singles, caps))
+
+    class ThreeSlots:                      # leave slot 3 of the 4-slot engine unused: rows above the occupied range stay idle
+        def __init__(self, e): self._e = e
+        def __getattr__(self, k): return getattr(self._e, k)
+        max_batch = 3
+    for chunk in (1, 5, 16):
+        cb = ContinuousBatcher(ThreeSlots(eng), eos_ids=eos, chunk=chunk)
+        got = cb.run(Request(ids, None if pv is None else pv.numpy(), None if grid is None else grid.numpy(), cap)
+                     for ids, pv, grid, cap in reqs)
+        assert [g.tolist() for g in got] == singles, chunk
+        assert cb.admissions >= 3                                               # slots were refilled while others kept decoding
+    # the static path still works after slot mode, and slot calls refuse misuse
+    out, n = eng.generate(reqs[0][0], np.array([len(reqs[0][0])], np.int32), reqs[0][1].numpy(), reqs[0][2].numpy(), max_new_tokens=7, eos_ids=eos)
+    assert out[0, :n[0]].tolist() == singles[0]
+    from dots_ocr_amd.engine import DotsEngineError
+    with pytest.raises(DotsEngineError):
+        eng.slots_decode(1)                                                     # no slot prefilled since the static call
+    eng.slots_prefill([2], reqs[8][0], [len(reqs[8][0])], [4])
+    with pytest.raises(DotsEngineError):
+        eng.slots_prefill([2], reqs[8][0], [len(reqs[8][0])], [4])             # occupied
+    with pytest.raises(DotsEngineError):
+        eng.slot_read(1, 4)                                                     # free
+    eng.slots_decode(4)
+    fin, lens = eng.slots_poll()
+    k = min(4, len(singles[8]))
+    assert fin.tolist() == [-1, -1, 1, -1] and lens[2] == k
+    assert eng.slot_read(2, 4).tolist() == singles[8][:k]
+    eng.slot_release(2)
+
+
+def test_continuous_batching_with_sampling_is_reproducible(setup):
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg, sd, eng = setup
+    reqs = []
+    for i in range(5):
+        pv, grid, seqs = _inputs(cfg, [(1, 4, 4)], 4, seed=200 + i)
+        reqs.append(Request(seqs[0].numpy().astype(np.int32), pv.numpy(), grid.numpy(), 6 + 3 * i))
+    eng.set_sampling(0.8, 0.9, 42)
+    try:
+        a = ContinuousBatcher(eng, chunk=4).run(reqs)
+        b = ContinuousBatcher(eng, chunk=4).run(reqs)
+    finally:
+        eng.set_sampling(0.0, 1.0, 0)
+    assert [x.tolist() for x in a] == [x.tolist() for x in b]
+    assert [len(x) for x in a] == [6 + 3 * i for i in range(5)]
+    greedy = ContinuousBatcher(eng, chunk=4).run(reqs)
+    assert [x.tolist() for x in greedy] != [x.tolist() for x in a]
