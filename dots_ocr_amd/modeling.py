@@ -78,10 +78,14 @@ class DotsOcrHipForCausalLM:
     # ------------------------------------------------------------------ generate
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
                  max_new_tokens: int = 128, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
-                 seed: int = 0, eos_token_id=None, pad_token_id=None, **_):
+                 seed: int = 0, eos_token_id=None, pad_token_id=None, continuous: Optional[bool] = None, **_):
         """HF-shaped generate.  Greedy by default (do_sample=False); with do_sample=True tokens are drawn on the GPU from
         softmax(logits / temperature) restricted to the top_p nucleus, reproducibly from `seed`.  Returns LongTensor
-        [B, T + n]: the (padded) prompt followed by the new tokens, positions after a sequence's EOS filled with pad_token_id."""
+        [B, T + n]: the (padded) prompt followed by the new tokens, positions after a sequence's EOS filled with pad_token_id.
+
+        More sequences than engine slots (B > max_batch) run with continuous batching: a slot is refilled with the next
+        sequence as soon as its page hits EOS instead of waiting for the slowest page of a static batch
+        (`continuous=True/False` forces either mode; greedy results are identical)."""
         import torch
         if do_sample and temperature > 0:
             self.engine.set_sampling(temperature, top_p, seed)
@@ -131,7 +135,23 @@ class DotsOcrHipForCausalLM:
         new_tokens = np.full((B, max_new_tokens), pad, dtype=np.int64)
         n_max = 0
         seq_patches = [int(sum(patch_off[g + 1] - patch_off[g] for g in img_of_seq[b])) for b in range(B)]
-        for sl in plan_batches(seq_patches, self.max_batch, self.max_patches):     # static batches within the engine's capacity
+        if continuous is None:
+            continuous = B > self.max_batch
+        if continuous:
+            from .scheduler import ContinuousBatcher, Request
+            reqs = []
+            for b in range(B):
+                if img_of_seq[b]:
+                    lo, hi = int(patch_off[img_of_seq[b][0]]), int(patch_off[img_of_seq[b][-1] + 1])
+                    pix = pv_dev[lo:hi] if pv_dev is not None else pv_host[lo:hi]
+                    reqs.append(Request(prompts[b], pix, grid[img_of_seq[b][0]:img_of_seq[b][-1] + 1], max_new_tokens))
+                else:
+                    reqs.append(Request(prompts[b], None, None, max_new_tokens))
+            outs = ContinuousBatcher(self.engine, eos_ids=eos).run(reqs)
+            for b, o in enumerate(outs):
+                new_tokens[b, :len(o)] = o
+                n_max = max(n_max, len(o))
+        for sl in ([] if continuous else plan_batches(seq_patches, self.max_batch, self.max_patches)):    # static batches within the engine's capacity
             imgs = [g for b in sl for g in img_of_seq[b]]
             lens = np.array([len(prompts[b]) for b in sl], np.int32)
             packed = np.concatenate([prompts[b] for b in sl])

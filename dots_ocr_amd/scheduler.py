@@ -49,6 +49,10 @@ class ContinuousBatcher:
         self.decode_steps = 0
         self.admissions = 0
         engine.set_eos(list(eos_ids))
+        fin, _ = engine.slots_poll()                 # start from an empty engine (e.g. after a failed run)
+        for s in range(self.n_slots):
+            if fin[s] >= 0:
+                engine.slot_release(s)
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: Request) -> int:

@@ -8,8 +8,11 @@ serves exactly that wire format from the MI355X engine, so those callers work un
 
     python -m dots_ocr_amd.server --model-path ./weights/DotsOCR --port 8000
 
-Concurrent requests (the reference client uses a ThreadPool of up to 64, parser.py:286-290) are collected by a batching
-worker into engine batches of up to `max_batch` pages with the same sampling parameters.
+Concurrent requests (the reference client uses a ThreadPool of up to 64, parser.py:286-290) share the engine the way they
+share a vLLM server: `ContinuousWorker` admits a request into a free sequence slot as soon as one exists and refills slots
+as pages finish (dots_ocr_amd/scheduler.py), for requests with the same sampling parameters; requests with other
+parameters wait for the running set to drain.  `BatchingWorker` (static batches through `model.generate`) remains for
+model objects without engine slots.
 """
 from __future__ import annotations
 
@@ -105,6 +108,81 @@ class BatchingWorker:
                     j.future.set_exception(e)
 
 
+class ContinuousWorker(BatchingWorker):
+    """Continuous batching over the engine's sequence slots; same submit()/close() surface as BatchingWorker.
+    `batches` records the number of occupied slots after every admission."""
+
+    def __init__(self, model, processor, max_batch: int = 8, max_wait_ms: float = 5.0, seed: int = 0, chunk: int = 16):
+        self.chunk = chunk
+        super().__init__(model, processor, max_batch=max_batch, max_wait_ms=max_wait_ms, seed=seed)
+
+    @staticmethod
+    def _key(j: _Job):
+        return (j.temperature, j.top_p)
+
+    def _finish(self, job: _Job, prompt_tokens: int, toks):
+        eos = set(self.model.config.eos_token_ids)
+        toks = [int(t) for t in toks]
+        text = self.processor.batch_decode([toks], skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
+        job.future.set_result({"text": text, "prompt_tokens": prompt_tokens, "completion_tokens": len(toks),
+                               "finish_reason": "stop" if toks and toks[-1] in eos else "length"})
+
+    def _run(self):
+        from collections import deque
+        from .scheduler import ContinuousBatcher, Request
+        engine = self.model.engine
+        waiting: "deque[_Job]" = deque()
+        cb, key = None, None
+        while True:
+            busy = cb is not None and not cb.idle
+            if not busy and not waiting:
+                job = self.q.get()                                   # nothing to do: block
+                if job is None:
+                    return
+                waiting.append(job)
+            while True:                                              # take whatever else has arrived
+                try:
+                    job = self.q.get_nowait()
+                except queue.Empty:
+                    break
+                if job is None:
+                    self._stop = True
+                    break
+                waiting.append(job)
+            if self._stop and not busy and not waiting:
+                return
+            try:
+                if not busy and waiting and (cb is None or key != self._key(waiting[0])):
+                    key = self._key(waiting[0])                      # switch sampling parameters between drained sets only
+                    self.seed += 1
+                    engine.set_sampling(key[0], key[1], self.seed)
+                    cb = ContinuousBatcher(engine, eos_ids=self.model.config.eos_token_ids, chunk=self.chunk)
+                # admit the FIFO prefix that shares the running parameters; a different request at the head makes the set drain
+                admitted = 0
+                while waiting and self._key(waiting[0]) == key and len(cb.pending) < 2 * cb.n_slots:
+                    job = waiting.popleft()
+                    try:
+                        inputs = self.processor(text=[job.text], images=[job.image] if job.image is not None else None,
+                                                padding=True, return_tensors="pt")
+                        ids = inputs["input_ids"][0].numpy()
+                        cb.submit(Request(ids, inputs.get("pixel_values"), None if "image_grid_thw" not in inputs
+                                          else inputs["image_grid_thw"].numpy(), job.max_tokens, tag=job))
+                        admitted += 1
+                    except Exception as e:                           # a bad request fails alone
+                        job.future.set_exception(e)
+                if cb is not None and not cb.idle:
+                    for _, req, toks in cb.step():
+                        self._finish(req.tag, int(req.input_ids.shape[0]), toks)
+                    if admitted:
+                        self.batches.append(len(cb.running))
+            except Exception as e:                                   # engine failure: fail everything in flight, start clean
+                if cb is not None:
+                    for _, (_, req) in list(cb.running.items()) + [(None, p) for p in cb.pending]:
+                        if not req.tag.future.done():
+                            req.tag.future.set_exception(e)
+                cb, key = None, None
+
+
 def _parse_messages(messages):
     """OpenAI chat messages -> (PIL image or None, chat-template text).  The reference client writes the image
     placeholder tokens into its text part itself (model/inference.py:33); if they are missing they are added."""
@@ -129,12 +207,14 @@ def _parse_messages(messages):
     return image, system + USER + body + END_USER + ASSISTANT
 
 
-def create_app(model, processor, model_name: str = "model", max_batch: int = 8, max_wait_ms: float = 5.0):
+def create_app(model, processor, model_name: str = "model", max_batch: int = 8, max_wait_ms: float = 5.0, continuous: Optional[bool] = None):
     from fastapi import FastAPI, HTTPException
     from fastapi.concurrency import run_in_threadpool
 
     app = FastAPI(title="dots.ocr MI355X engine")
-    worker = BatchingWorker(model, processor, max_batch=max_batch, max_wait_ms=max_wait_ms)
+    if continuous is None:
+        continuous = hasattr(model, "engine")
+    worker = (ContinuousWorker if continuous else BatchingWorker)(model, processor, max_batch=max_batch, max_wait_ms=max_wait_ms)
     app.state.worker = worker
 
     @app.get("/health")
@@ -188,6 +268,7 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--served-model-name", default="model")
     ap.add_argument("--max-batch", type=int, default=8)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--static-batching", action="store_true", help="static batches through model.generate instead of continuous batching")
     a = ap.parse_args(argv)
     import uvicorn
     from .modeling import DotsOcrHipForCausalLM
@@ -198,7 +279,7 @@ def main(argv: Optional[List[str]] = None):
     else:
         model = DotsOcrHipForCausalLM.from_pretrained(a.model_path, device=a.device, max_batch=a.max_batch)
         proc = DotsOcrProcessor.from_pretrained(a.model_path, engine=model.engine)
-    uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch), host=a.host, port=a.port)
+    uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch, continuous=not a.static_batching), host=a.host, port=a.port)
 
 
 if __name__ == "__main__":

@@ -235,48 +235,8 @@ def test_continuous_batcher_admission_and_refill_with_a_fake_engine():
     import numpy as np
     from dots_ocr_amd.scheduler import ContinuousBatcher, Request
 
-    class FakeEngine:
-        max_batch, max_patches, max_prefill_tokens, max_seq_len = 3, 100, 64, 128
-
-        def __init__(self):
-            self.slots = {}            # slot -> [prompt, cap, produced]
-            self.log = []
-
-        def set_eos(self, eos): self.eos = list(eos)
-        def synchronize(self): pass
-
-        def vit_forward(self, pv, grid, on_device=False):
-            self.log.append(("vit", int(np.asarray(grid)[:, 1:].prod(axis=1).sum()), len(pv)))
-
-        def slots_prefill(self, slots, ids, lens, caps):
-            assert sum(lens) == len(ids) <= self.max_prefill_tokens
-            off = 0
-            for s, n, c in zip(slots, lens, caps):
-                assert s not in self.slots
-                self.slots[s] = [ids[off:off + n].copy(), c, 1]
-                off += n
-            self.log.append(("prefill", tuple(slots)))
-
-        def slots_decode(self, n):
-            assert self.slots
-            for st in self.slots.values():
-                st[2] = min(st[1], st[2] + n)
-            self.log.append(("decode", n, tuple(sorted(self.slots))))
-
-        def slots_poll(self):
-            fin = np.full(3, -1, np.int32)
-            lens = np.zeros(3, np.int32)
-            for s, (_, cap, n) in self.slots.items():
-                fin[s], lens[s] = int(n >= cap), n
-            return fin, lens
-
-        def slot_read(self, s, capacity):
-            prompt, _, n = self.slots[s]
-            return (int(prompt[0]) + np.arange(n, dtype=np.int32))[:capacity]      # "tokens" identify the request
-
-        def slot_release(self, s): del self.slots[s]
-
-    eng = FakeEngine()
+    from fakes import FakeSlotEngine
+    eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(200))       # "tokens" identify the request
     cb = ContinuousBatcher(eng, eos_ids=(7,), chunk=4)
     assert eng.eos == [7]
     def req(first, n_tok, cap, patches=0):

@@ -314,3 +314,25 @@ def test_continuous_batching_with_sampling_is_reproducible(setup):
     assert [len(x) for x in a] == [6 + 3 * i for i in range(5)]
     greedy = ContinuousBatcher(eng, chunk=4).run(reqs)
     assert [x.tolist() for x in greedy] != [x.tolist() for x in a]
+
+
+def test_hf_shaped_generate_switches_to_continuous_batching_for_many_pages():
+    """The object the parser calls (parser.py:110): 7 pages through a 2-slot engine, processor output (left padded, GPU
+    preprocessing) in, HF-shaped LongTensor out; the continuous and the static schedules give the same tokens."""
+    from dots_ocr_amd.modeling import DotsOcrHipForCausalLM
+    from dots_ocr_amd.processing import DotsOcrProcessor
+    from dots_ocr_amd.synthetic import synth_page
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    model = DotsOcrHipForCausalLM.from_random(cfg, seed=5, max_batch=2, max_seq_len=512, max_patches=2048)
+    proc = DotsOcrProcessor(cfg, engine=model.engine)
+    sizes = [(140, 84), (56, 56), (112, 84), (84, 140), (56, 112), (168, 56), (112, 112)]
+    pages = [synth_page(i, s) for i, s in enumerate(sizes)]
+    msgs = [[{"role": "user", "content": [{"type": "image", "image": p}, {"type": "text", "text": "read"}]}] for p in pages]
+    text = [proc.apply_chat_template(m, tokenize=False, add_generation_prompt=True) for m in msgs]
+    inputs = proc(text=text, images=pages, padding=True, return_tensors="pt")
+    assert inputs["pixel_values"].is_cuda
+    a = model.generate(**inputs, max_new_tokens=24)                       # B=7 > 2 slots -> continuous
+    b = model.generate(**inputs, max_new_tokens=24, continuous=False)     # static batches of 2
+    assert a.shape[0] == 7 and torch.equal(a, b)
+    assert torch.equal(a[:, :inputs["input_ids"].shape[1]], inputs["input_ids"])
+    model.engine.close()

@@ -100,3 +100,53 @@ def test_bad_requests(client):
     assert c.post("/v1/chat/completions", json=_payload(synth_page(0, (56, 56)), stream=True)).status_code == 400
     bad = {"messages": [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": "data:image/png;base64,@@@"}}]}]}
     assert c.post("/v1/chat/completions", json=bad).status_code == 400
+
+
+class _SlotModel:
+    """Model object with engine slots (stand-in engine from tests/fakes.py): the server picks ContinuousWorker for it."""
+
+    def __init__(self, proc, cfg):
+        from fakes import FakeSlotEngine
+        self.config = cfg
+        self.samplings = []
+
+        def script(prompt):
+            n_img = int((prompt == cfg.image_token_id).sum())
+            t, p, _ = self.engine.sampling
+            return proc.tokenizer.encode(f"{n_img}|{t:g}|{p:g}|" + "x" * (n_img % 7)) + [cfg.eos_token_ids[0]]
+        self.engine = FakeSlotEngine(script, max_batch=3, max_patches=4096, max_prefill_tokens=4096, max_seq_len=2048)
+
+
+def test_continuous_worker_keeps_slots_full_and_separates_sampling_parameters():
+    from dots_ocr_amd.server import ContinuousWorker, create_app
+    cfg = DotsConfig.tiny()
+    proc = DotsOcrProcessor(cfg)
+    model = _SlotModel(proc, cfg)
+    app = create_app(model, proc, model_name="model", max_batch=3)
+    with TestClient(app) as c:
+        assert isinstance(app.state.worker, ContinuousWorker)
+        app.state.worker.chunk = 2
+        sizes = [(140, 84), (56, 56), (112, 84), (84, 140), (56, 112), (168, 56), (112, 112), (56, 84)]
+        results = [None] * len(sizes)
+
+        def go(i):
+            kw = {"temperature": 0} if i % 4 == 3 else {}
+            results[i] = c.post("/v1/chat/completions", json=_payload(synth_page(i, sizes[i]), **kw))
+        th = [threading.Thread(target=go, args=(i,)) for i in range(len(sizes))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for i, r in enumerate(results):
+            assert r.status_code == 200, r.text
+            d = r.json()
+            n_img, temp, top_p, _ = d["choices"][0]["message"]["content"].split("|")
+            w, h = sizes[i]
+            assert int(n_img) == (h // 14) * (w // 14) // 4
+            assert (float(temp), float(top_p)) == ((0.0, 0.9) if i % 4 == 3 else (0.1, 0.9))     # each ran under its own parameters
+            assert d["choices"][0]["finish_reason"] == "stop" and d["usage"]["prompt_tokens"] > int(n_img)
+        eng = model.engine
+        pre = [e[1] for e in eng.log if e[0] == "prefill"]
+        assert sum(len(p) for p in pre) == len(sizes) and all(len(p) <= 3 for p in pre)
+        assert max(app.state.worker.batches) <= 3 and not eng.slots
+        # a capped request reports "length"
+        d = c.post("/v1/chat/completions", json=_payload(synth_page(0, sizes[0]), max_completion_tokens=3)).json()
+        assert d["choices"][0]["finish_reason"] == "length" and d["usage"]["completion_tokens"] == 3
