@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* _
 // Split-KV decode attention.  grid (n_splits, Hkv, B), 4 waves; wave w walks pages split*4 + w,
 // += 4*n_splits.  All `group` (<= 16) query heads of one kv head share every K/V load (GQA).
 // Output per (b, hkv, split): unnormalised O [group][128] fp32, (m, l) [group].
+// n_splits is an engine constant (from max_seq_len), so which pages a split sums — and with it every bit of the
+// result — depends on the sequence's own context only, not on what else is in the batch or on the schedule.
+// Splits past the context's last page exit at once and are not read by the combine kernel.
 __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
                                                           const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
                                                           int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
     const int ctx = ctx_len[b] + 1;                       // includes the token appended this step
     const int n_pages = (ctx + PAGE - 1) / PAGE;
+    if (split * 4 >= n_pages) return;
 
     // Q fragments (B operand): lane (j = i, g) holds Q[hkv*group + j][32kk + 8g .. +7]; zero rows j >= group
     bf16x8 qf[4];
@@ -252,17 +256,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
 // The split weights are computed once by the first wave (lane = split), kept in LDS; the per-feature
 // accumulation then issues its n_splits loads independently (unrolled by 4), not as a dependent chain.
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                                  bf16_t* __restrict__ out, int Hq, int Hkv, int n_splits) {
+                                                                  const int32_t* __restrict__ ctx_len, bf16_t* __restrict__ out, int Hq,
+                                                                  int Hkv, int n_splits) {
     __shared__ float wts[64];
     __shared__ float inv_l;
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const int n_used = min(n_splits, ((ctx_len[b] + 1 + PAGE - 1) / PAGE + 3) / 4);       // splits that own at least one page
     const int group = Hq / Hkv, hkv = head / group, j = head % group;
     const size_t base0 = (((size_t)b * Hkv + hkv) * n_splits) * group + j;     // + s*group
     if (d < 64) {
         float m = -1e30f, l = 0.f;
-        if (d < n_splits) { m = part_ml[(base0 + (size_t)d * group) * 2]; l = part_ml[(base0 + (size_t)d * group) * 2 + 1]; }
+        if (d < n_used) { m = part_ml[(base0 + (size_t)d * group) * 2]; l = part_ml[(base0 + (size_t)d * group) * 2 + 1]; }
         const float mg = wave_max(m);
-        const float f = d < n_splits ? __builtin_amdgcn_exp2f(m - mg) : 0.f;
+        const float f = d < n_used ? __builtin_amdgcn_exp2f(m - mg) : 0.f;
         wts[d] = f;
         const float lsum = wave_sum(l * f);
         if (d == 0) inv_l = 1.0f / lsum;
@@ -272,13 +278,13 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
     const size_t stride = (size_t)group * 128;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int s = 0;
-    for (; s + 4 <= n_splits; s += 4) {
+    for (; s + 4 <= n_used; s += 4) {
         a0 += po[(size_t)s * stride] * wts[s];
         a1 += po[(size_t)(s + 1) * stride] * wts[s + 1];
         a2 += po[(size_t)(s + 2) * stride] * wts[s + 2];
         a3 += po[(size_t)(s + 3) * stride] * wts[s + 3];
     }
-    for (; s < n_splits; ++s) a0 += po[(size_t)s * stride] * wts[s];
+    for (; s < n_used; ++s) a0 += po[(size_t)s * stride] * wts[s];
     out[frag_off(b, head * 128 + d)] = f2bf(((a0 + a1) + (a2 + a3)) * inv_l);     // fragment-order input of the o projection
 }
 
@@ -470,9 +476,9 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
     return hipGetLastError();
 }
 
-hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
+hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, const int32_t* ctx_len, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits) {
-    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, out, Hq, Hkv, n_splits);
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, ctx_len, out, Hq, Hkv, n_splits);
     return hipGetLastError();
 }
 

@@ -714,7 +714,7 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
                           e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq, Hkv, c.rms_norm_eps));
         if (n_slabs) cur ^= 1;
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
-        CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->d_att, B, Hq, Hkv, n_splits));
+        CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
         CK(launch_dec_proj(s, e->d_att, L.o_wd, hb[cur], nullptr, 1, B, H, Nq));
         CK(launch_dec_gateup(s, hb[cur], L.ln2, L.w13_wd, e->d_act, B, H, I, c.rms_norm_eps));
         CK(launch_dec_proj(s, e->d_act, L.down_wd, hb[cur], e->d_slabs, down_split, B, H, I));
@@ -851,7 +851,7 @@ int dots_decode_step(DotsEngine* e) {
     int max_ctx = 0;
     for (int b = 0; b < e->B; ++b) max_ctx = std::max(max_ctx, e->h_prompt_lens[b] + e->steps_done + 1);
     if (max_ctx >= e->cfg.max_seq_len) return e->fail(DOTS_E_CAPACITY, "sequence reached max_seq_len");
-    RET(decode_step_launches(e, splits_for_ctx(max_ctx)));
+    RET(decode_step_launches(e, splits_for_ctx(e->cfg.max_seq_len)));
     e->steps_done += 1;
     return DOTS_OK;
 }
@@ -880,7 +880,7 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
 
     // ---- decode loop: one captured graph replayed max_new_tokens-1 times
     CK(hipEventRecord(e->ev[4], s));
-    const int n_splits = splits_for_ctx(max_prompt + max_new_tokens);
+    const int n_splits = splits_for_ctx(e->cfg.max_seq_len);       // engine constant: results do not depend on the batch
     const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -958,12 +958,9 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     if (n_steps < 1) return e->fail(DOTS_E_INVALID, "n_steps must be >= 1");
     CK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
-    int rows = 0, limit = 0;
+    int rows = 0;
     for (int b = 0; b < e->cfg.max_batch; ++b)
-        if (e->slot_active[b]) {
-            rows = b + 1;
-            limit = std::max(limit, e->slot_limit[b]);
-        }
+        if (e->slot_active[b]) rows = b + 1;
     if (!rows) return e->fail(DOTS_E_STATE, "every slot is free");
     if (e->sel_dirty) {
         int32_t sel[16];
@@ -971,7 +968,7 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
         CK(hipMemcpyAsync(e->d_sel, sel, 16 * 4, hipMemcpyHostToDevice, s));
         e->sel_dirty = false;
     }
-    const int n_splits = splits_for_ctx(limit);
+    const int n_splits = splits_for_ctx(e->cfg.max_seq_len);
     e->B = rows;
     static const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
     hipGraphExec_t exec = nullptr;

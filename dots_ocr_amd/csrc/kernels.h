@@ -59,7 +59,7 @@ hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const float* slabs,
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
                               int B, int Hq, int Hkv, int n_splits, float scale);
-hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, bf16_t* out,
+hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, const int32_t* ctx_len, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits);
 // Per-step token bookkeeping state (device pointers), shared by the arg-max and the sampling kernels.
 //   sel     rows (slots) to act on this call, or nullptr = all B rows
