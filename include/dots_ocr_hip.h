@@ -194,6 +194,11 @@ int dots_op_gemm_skinny(DotsEngine* e, const void* X_dev, const void* W_dev, voi
 
 /* MFMA fragment-layout / LDS-DMA probe (csrc/probe_mfma.hip; tests/test_mfma_layout.py). */
 int dots_probe_mfma(int which, const void* A, const void* Bt, void* D, void* stream);
+/* Device-wide barrier probe inside one persistent kernel (csrc/probe_sync.hip): n_barriers bounded-spin barriers over
+ * n_wg workgroups, each followed by cross-workgroup reads of freshly published data.  mode: 0 no fences, 1 agent-scope
+ * fences, 2 nontemporal accesses, 3 agent-scope atomic accesses.  *ms_out = kernel time, stats_out[0] = stale reads,
+ * stats_out[1] = barrier timeouts (the spin is bounded, the probe cannot hang). */
+int dots_probe_grid_barrier(int n_wg, int threads, int n_barriers, int mode, int lds_bytes, float* ms_out, int32_t* stats_out);
 
 #ifdef __cplusplus
 }
