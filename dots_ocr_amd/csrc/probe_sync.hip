@@ -104,3 +104,35 @@ extern "C" int dots_probe_grid_barrier(int n_wg, int threads, int n_barriers, in
     (void)hipFree(buf);
     return (int)e;
 }
+
+// ------------------------------------------------------------------------------------------------
+// CU-mask probe: which CUs does a stream created with hipExtStreamCreateWithCUMask run on?  Every workgroup records its
+// raw HW_ID and XCC_ID registers and spins ~20 us so that the dispatcher has to spread the grid; the host counts
+// distinct (xcc, se, sh, cu) tuples.  Used to choose the masks of the decode / admission streams.
+namespace {
+__global__ void probe_cu_id_kernel(uint32_t* out, int spin) {
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+        out[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_REG_XCC_ID
+    }
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+// mask == nullptr: the null stream (all CUs).  ids_out: uint32 [n_wg][2] raw register values.
+extern "C" int dots_probe_cu_mask(const uint32_t* mask, int words, int n_wg, int threads, int lds_bytes, uint32_t* ids_out) {
+    if (n_wg < 1 || n_wg > 65536 || !ids_out) return -1;
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (mask && (e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask)) != hipSuccess) return (int)e;
+    uint32_t* d = nullptr;
+    if ((e = hipMalloc(&d, (size_t)n_wg * 8)) != hipSuccess) return (int)e;
+    if (lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)probe_cu_id_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(probe_cu_id_kernel, dim3(n_wg), dim3(threads), lds_bytes, s, d, 200);
+    e = hipStreamSynchronize(s);
+    (void)hipMemcpy(ids_out, d, (size_t)n_wg * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (s) (void)hipStreamDestroy(s);
+    return (int)e;
+}

@@ -92,6 +92,7 @@ def _prototypes(lib):
         "dots_op_gemm_skinny": (i32, [vp, vp, vp, vp, i32, i32, i32]),
         "dots_probe_mfma": (i32, [i32, vp, vp, vp, vp]),
         "dots_probe_grid_barrier": (i32, [i32, i32, i32, i32, i32, P(f32), P(i32)]),
+        "dots_probe_cu_mask": (i32, [P(C.c_uint32), i32, i32, i32, i32, P(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -106,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
-    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma", "dots_probe_grid_barrier",
+    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
 
 

@@ -199,6 +199,9 @@ int dots_probe_mfma(int which, const void* A, const void* Bt, void* D, void* str
  * fences, 2 nontemporal accesses, 3 agent-scope atomic accesses.  *ms_out = kernel time, stats_out[0] = stale reads,
  * stats_out[1] = barrier timeouts (the spin is bounded, the probe cannot hang). */
 int dots_probe_grid_barrier(int n_wg, int threads, int n_barriers, int mode, int lds_bytes, float* ms_out, int32_t* stats_out);
+/* CU-mask probe: runs n_wg workgroups on a stream created with hipExtStreamCreateWithCUMask(mask) (NULL: all CUs) and
+ * returns each workgroup's raw HW_ID / XCC_ID registers, uint32 [n_wg][2]. */
+int dots_probe_cu_mask(const uint32_t* mask, int words, int n_wg, int threads, int lds_bytes, uint32_t* ids_out_host);
 
 #ifdef __cplusplus
 }
