@@ -18,6 +18,15 @@
 // fetched into registers before this tile's MFMAs and written to LDS after them (guide T14),
 // one barrier per tile.  The loop is software-pipelined by one stage (QK of tile j and PV of tile j-1
 // form one 32-MFMA block, then the softmax of tile j); s_setprio around the MFMA blocks measured null.
+//
+// MODE 1 (8-wave workgroups, default): the kernel needs > 200 VGPRs, so a CU holds ONE workgroup = 2 waves per SIMD, and
+// with one workgroup-wide barrier per tile both waves of a SIMD enter their MFMA block together and their softmax
+// together (SQ counters: MFMA pipe 52 % busy, waves 35 % parked).  Here waves 4-7 run half a tile period behind waves
+// 0-3 (one extra barrier at the start, barriers after the MFMA block and after the softmax): while one wave of a SIMD
+// issues its 32 MFMAs the other does its softmax on the VALU.  K/V tiles are then alive for 1.5 periods: three LDS
+// buffers (96 KB), tile t staged by the early half during its iteration t-1 and by the late half during t-2.  Together
+// with the explicit LDS look-ahead of the MFMA block: 1099 -> 1163 TFLOP/s (same-box A/B, profiles/r01_final2_*);
+// either change alone gains nothing.  Bit-identical results (same accumulation order).
 #include <cstdlib>
 
 #include "common.h"
@@ -30,12 +39,16 @@ constexpr int VT_BYTES = 128 * 128;   // V^T tile
 constexpr int BUF_BYTES = KT_BYTES + VT_BYTES;
 constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64; THR = 0 reproduces the textbook rescale-every-tile
 
-template <bool CAUSAL, int NW>
+template <bool CAUSAL, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
     bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
     float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    // MODE 0: one barrier per tile, hipcc's own LDS-read placement (the round-1 schedule, kept for A/B runs and for the
+    // 4-wave variant).  MODE 1: ping-pong halves + LDS fragments requested one MFMA group ahead.
+    constexpr bool PINGPONG = MODE == 1;
+    static_assert(!PINGPONG || NW == 8, "ping-pong pairs wave w with wave w + 4 on the same SIMD");
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 (3 with PINGPONG) x BUF_BYTES
 
     const QBlock qb = blocks[xcd_remap(blockIdx.x, n_items)];
     const int h = qb.head;
@@ -112,47 +125,56 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
     const int v_row_off = l31 * 128;                 // + dt*32*128
     const int v_sw = (l31 >> 1) & 7;
 
-    auto pv = [&](int buf) {                         // O^T += V^T(buf) . pf : 4 d tiles x 4 key slabs
-        const char* vb = smem + buf * BUF_BYTES + KT_BYTES;
+    auto k_frag = [&](const char* kb, int t, int ks) {
+        return *reinterpret_cast<const bf16x8*>(kb + t * 32 * 256 + k_row_off + (((ks * 2 + hi) ^ k_sw) << 4));
+    };
+    auto v_frag = [&](const char* vb, int dt, int sl) {
+        return *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_row_off + (((sl * 2 + hi) ^ v_sw) << 4));
+    };
+
+    // O^T += V^T(vb) . pf : 4 d tiles x 4 key slabs, hipcc's own placement of the LDS reads
+    auto pv = [&](const char* vb) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + dt * 32 * 128 + v_row_off + (((sl * 2 + hi) ^ v_sw) << 4));
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sl], o[dt], 0, 0, 0);
-            }
+            for (int sl = 0; sl < 4; ++sl) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vb, dt, sl), pf[sl], o[dt], 0, 0, 0);
     };
 
-    load_k(0);
-    write_k(0);
-    __syncthreads();
-
-    // Software-pipelined by one stage: iteration j issues ONE block of 32 MFMAs — S^T(j) = K(j).Q^T and
-    // O^T += V^T(j-1).P^T(j-1) — then runs the softmax of tile j on the VALU.  The two waves of a SIMD fall into
-    // antiphase (one in its MFMA block while the other is in its VALU block), which a strict QK -> softmax -> PV
-    // order per tile cannot do.  V(j) is staged during iteration j (it is first read in iteration j+1), K(j+1) too,
-    // so two LDS buffers and one barrier per tile still suffice:
-    //   K buffer (j+1)&1 was last read by QK(j-1), V buffer j&1 by PV(j-2) — both before the previous barrier.
-    for (int j = 0; j < n_tiles; ++j) {
-        const bool has_next = (j + 1 < n_tiles);
-        if (has_next) load_k(j + 1);
-        load_v(j);
-        const char* kb = smem + (j & 1) * BUF_BYTES;
-
-        // ---- S^T = K . Q^T : 2 key tiles x 8 k-steps ----
-        f32x16 s[2];
+    // ONE block of 32 MFMAs with explicit LDS look-ahead: S^T(j) = K(j).Q^T (16) then O^T += V^T(j-1).P^T(j-1) (16), as
+    // 8 groups of 4.  The 4 fragments of group g+1 are requested before the MFMAs of group g issue (left alone, hipcc
+    // puts each ds_read right in front of its MFMA and a lone wave waits out the LDS latency 16 times per tile); the
+    // sched_group_barriers pin that order.  Two groups of look-ahead measured slower (1077 vs 1102 TFLOP/s).  The
+    // accumulation order per accumulator is the same as in the plain loops (ks, then key slab).
+    auto mfma_block = [&](const char* kb, const char* vb, bool has_pv, f32x16 (&s)[2]) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        bf16x8 fr[2][4];
+        auto fetch = [&](int g, bf16x8 (&f)[4]) {        // g < 4: K (t, ks) = (i & 1, 2g + (i >> 1));  g >= 4: V^T (dt, sl) = (i, g - 4)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + t * 32 * 256 + k_row_off + (((ks * 2 + hi) ^ k_sw) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) f[i] = g < 4 ? k_frag(kb, i & 1, 2 * g + (i >> 1)) : v_frag(vb, i, g - 4);
+        };
+        const int n_groups = has_pv ? 8 : 4;             // no PV before the first tile
+        fetch(0, fr[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < n_groups) {
+                if (g + 1 < n_groups) fetch(g + 1, fr[(g + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (g < 4) s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][i], qf[2 * g + (i >> 1)], s[i & 1], 0, 0, 0);
+                    else o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][i], pf[g - 4], o[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (the next group) ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this group's 4 MFMAs
             }
         }
-        if (j > 0) pv((j - 1) & 1);
+    };
 
+    // mask + online softmax of tile j: S^T (fp32) -> P^T (bf16, `pf`), running max / sum, deferred rescale of O
+    auto softmax_tile = [&](int j, f32x16 (&s)[2]) {
         // ---- mask (only the ragged last tile / the causal diagonal) ----
         const int key0 = j * 64;
         bool need_mask = (key0 + 64 > n);
@@ -168,7 +190,6 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
                     s[t][r] = ok ? s[t][r] : -INFINITY;
                 }
         }
-
         // ---- online softmax (per q = lane&31; the two half-waves hold disjoint key subsets) ----
         float mx = s[0][0];
 #pragma unroll
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // Deferred rescale (guide T13): keep the old running max while it is exceeded by at most 2^RESCALE_THR
         // for every row of the wave; P is then bounded by 2^RESCALE_THR instead of 1 (fp32 sum and bf16's 8-bit
-        // exponent have the headroom).  When the branch fires, O (complete up to tile j-1: its PV was issued above)
+        // exponent have the headroom).  When the branch fires, O (complete up to tile j-1: its PV was issued before)
         // and l — everything still expressed against the old max — are scaled exactly once, before this tile's P is
         // formed against the new max.
         const float m_cand = mx * scale_log2e;
@@ -208,12 +229,79 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
                 pf[t * 2 + u] = __builtin_bit_cast(bf16x8, pk);
             }
         l_run += psum;
+    };
 
-        if (has_next) write_k((j + 1) & 1);
-        write_v(j & 1);
+    if constexpr (PINGPONG) {
+        // Waves 4-7 ("late") run half a tile period behind waves 0-3: one extra barrier at the start, then a barrier after
+        // the MFMA block and one after the softmax.  Tile t (K and V^T together) lives in buffer t % 3; the early half
+        // stages its share during its iteration t-1, the late half during its iteration t-2 (tile 1: in the prologue), so
+        // every share is in LDS one barrier before the first MFMA block that reads it, and a buffer is overwritten only
+        // after both halves' PV of the tile it held.
+        const bool late = w >= NW / 2;                   // wave-uniform
+        load_k(0);
+        load_v(0);
+        write_k(0);
+        write_v(0);
+        if (late && n_tiles > 1) {
+            load_k(1);
+            load_v(1);
+            write_k(1);
+            write_v(1);
+        }
         __syncthreads();
+        if (late) __syncthreads();
+        int b_cur = 0, b_prev = 2, b_stage = late ? 2 : 1;          // j % 3, (j - 1) % 3, (j + 1 or 2) % 3
+        for (int j = 0; j < n_tiles; ++j) {
+            const int t_stage = j + (late ? 2 : 1);
+            const bool has_stage = t_stage < n_tiles;
+            if (has_stage) {
+                load_k(t_stage);
+                load_v(t_stage);
+            }
+            f32x16 s[2];
+            mfma_block(smem + b_cur * BUF_BYTES, smem + b_prev * BUF_BYTES + KT_BYTES, j > 0, s);
+            __syncthreads();                             // the other half of the workgroup starts its MFMA block
+            softmax_tile(j, s);
+            if (has_stage) {
+                write_k(b_stage);
+                write_v(b_stage);
+            }
+            __syncthreads();
+            b_prev = b_cur;
+            b_cur = b_cur == 2 ? 0 : b_cur + 1;
+            b_stage = b_stage == 2 ? 0 : b_stage + 1;
+        }
+        pv(smem + b_prev * BUF_BYTES + KT_BYTES);
+        if (!late) __syncthreads();                      // pairs with the late half's last barrier
+    } else {
+        // Software-pipelined by one stage: iteration j issues ONE block of 32 MFMAs — S^T(j) = K(j).Q^T and
+        // O^T += V^T(j-1).P^T(j-1) — then runs the softmax of tile j on the VALU.  V(j) is staged during iteration j
+        // (it is first read in iteration j+1), K(j+1) too, so two LDS buffers and one barrier per tile suffice:
+        //   K buffer (j+1)&1 was last read by QK(j-1), V buffer j&1 by PV(j-2) — both before the previous barrier.
+        load_k(0);
+        write_k(0);
+        __syncthreads();
+        for (int j = 0; j < n_tiles; ++j) {
+            const bool has_next = (j + 1 < n_tiles);
+            if (has_next) load_k(j + 1);
+            load_v(j);
+            const char* kb = smem + (j & 1) * BUF_BYTES;
+            f32x16 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(kb, t, ks), qf[ks], s[t], 0, 0, 0);
+            }
+            if (j > 0) pv(smem + ((j - 1) & 1) * BUF_BYTES + KT_BYTES);
+            softmax_tile(j, s);
+            if (has_next) write_k((j + 1) & 1);
+            write_v(j & 1);
+            __syncthreads();
+        }
+        pv(smem + ((n_tiles - 1) & 1) * BUF_BYTES + KT_BYTES);
     }
-    pv((n_tiles - 1) & 1);
 
     // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -240,18 +328,21 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
     if (Hq % Hkv != 0) return hipErrorInvalidValue;
     const float c = scale * 1.44269504088896340736f;
     dim3 grid(n_blocks);                      // n_blocks = work items (seq x head x query block)
+    // DOTS_OCR_ATTN_MODE: 1 (default) = ping-pong halves + LDS fragment look-ahead, 0 = the round-1 schedule
+    static const int mode = getenv("DOTS_OCR_ATTN_MODE") ? atoi(getenv("DOTS_OCR_ATTN_MODE")) : 1;
+    auto go = [&](auto kern, int threads, int lds) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+        return hipGetLastError();
+    };
     if (flash_rows_per_block() == 256) {
-        if (causal)
-            hipLaunchKernelGGL((flash_attn_kernel<true, 8>), grid, dim3(512), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
-        else
-            hipLaunchKernelGGL((flash_attn_kernel<false, 8>), grid, dim3(512), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
-    } else {
-        if (causal)
-            hipLaunchKernelGGL((flash_attn_kernel<true, 4>), grid, dim3(256), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
-        else
-            hipLaunchKernelGGL((flash_attn_kernel<false, 4>), grid, dim3(256), 0, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+        if (mode == 1) return causal ? go(flash_attn_kernel<true, 8, 1>, 512, 3 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 1>, 512, 3 * BUF_BYTES);
+        return causal ? go(flash_attn_kernel<true, 8, 0>, 512, 2 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 0>, 512, 2 * BUF_BYTES);
     }
-    return hipGetLastError();
+    return causal ? go(flash_attn_kernel<true, 4, 0>, 256, 2 * BUF_BYTES) : go(flash_attn_kernel<false, 4, 0>, 256, 2 * BUF_BYTES);
 }
 
 // query rows per work item: 256 (8 waves sharing each K/V tile, 1 workgroup per CU; default: half the global->LDS staging

@@ -18,7 +18,7 @@ from dots_ocr_amd.engine import Engine  # noqa: E402
 iters = 5
 if "--iters" in sys.argv:
     iters = int(sys.argv[sys.argv.index("--iters") + 1])
-what = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["gemm", "flash"]
+what = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["gemm", "flash"]   # --iters N, --seqs N take numbers
 eng = Engine(DotsConfig.tiny(), max_batch=2, max_seq_len=256, max_patches=256, max_prefill_tokens=256)
 
 
@@ -46,7 +46,8 @@ if "gemm" in what:
 
 if "flash" in what:
     H, n = 12, 19824
-    lens = [n, n]
+    seqs = int(sys.argv[sys.argv.index("--seqs") + 1]) if "--seqs" in sys.argv else 2
+    lens = [n] * seqs
     T = sum(lens)
     Tpad = sum((x + 63) // 64 * 64 for x in lens)
     q = torch.randn(H, T, 128, device="cuda").bfloat16()
