@@ -5,7 +5,10 @@ Same constructor keywords, methods, on-disk outputs and result dicts as the refe
 HF ``AutoModelForCausalLM`` + flash-attn on CUDA (parser.py:62-117) the model object is
 ``DotsOcrHipForCausalLM`` (hand-written gfx950 kernels behind a C ABI) and the processor is
 ``DotsOcrProcessor``.  ``use_hf=True`` therefore selects the HIP engine.  PDF parsing feeds ALL pages
-of a document to one batched ``generate`` (the reference forces one page at a time, parser.py:279-282).
+of a document to the engine at once (the reference forces one page at a time, parser.py:279-282): with the
+real engine as a pipeline — host threads prepare pages ahead of the GPU, the continuous batcher keeps the
+sequence slots full, finished pages are post-processed (layout clean-up, drawing, markdown, file writes:
+parser.py:171-262) on host threads while the GPU decodes the others.
 The vLLM HTTP client path (use_hf=False, model/inference.py) talks to an external server and is kept
 for API compatibility only.
 """
@@ -160,9 +163,46 @@ class DotsOCRParser:
         result["file_path"] = input_path
         return [result]
 
+    def _parse_pages_pipelined(self, images, filename, prompt_mode, save_dir, input_path):
+        """prepare (host threads) -> preprocess + admit (this thread, GPU) -> decode (GPU, continuous batching) -> post-process
+        (host threads).  Only this thread talks to the engine (one handle per GPU, not thread-safe)."""
+        from multiprocessing.pool import ThreadPool
+        from .scheduler import ContinuousBatcher, Request
+        engine = self.model.engine
+        engine.set_sampling(0.0, 1.0, 0)                                         # the reference's HF path is greedy (parser.py:110)
+        eos = list(self.model.config.eos_token_ids)
+        cb = ContinuousBatcher(engine, eos_ids=eos)
+        n = len(images)
+        results = [None] * n
+        with ThreadPool(max(1, min(8, self.num_thread, n))) as prep_pool, ThreadPool(max(1, min(8, self.num_thread, n))) as post_pool:
+            prep = [prep_pool.apply_async(self._prepare, (im, prompt_mode, "pdf", None, False)) for im in images]
+            prepared, posts, nxt = {}, {}, 0
+            while nxt < n or not cb.idle:
+                # admit pages in order, without stalling the GPU on a page whose host preparation is still running
+                while nxt < n and len(cb.pending) < cb.n_slots and (prep[nxt].ready() or cb.idle):
+                    image, prompt, mn, mx = prepared[nxt] = prep[nxt].get()
+                    inputs = self._build_inputs([image], [prompt])
+                    ids = inputs["input_ids"][0]
+                    ids = ids[inputs["attention_mask"][0].bool()].cpu().numpy()
+                    cb.submit(Request(ids, inputs.get("pixel_values"), None if "image_grid_thw" not in inputs
+                                      else inputs["image_grid_thw"].cpu().numpy(), self.hf_max_new_tokens, tag=nxt))
+                    nxt += 1
+                for _, req, toks in cb.step():
+                    i = req.tag
+                    toks = [int(t) for t in toks]
+                    text = self.processor.batch_decode([toks], skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
+                    image, _, mn, mx = prepared.pop(i)
+                    posts[i] = post_pool.apply_async(self._save, (text, images[i], image, prompt_mode, save_dir, f"{filename}_page_{i}", i, mn, mx))
+            for i, fut in posts.items():
+                results[i] = fut.get()
+                results[i]["file_path"] = input_path
+        return results
+
     def parse_pages(self, images, filename, prompt_mode, save_dir, input_path=None):
-        """All pages of one document through ONE batched generate (engine backend) — the caller-side half of
-        page batching."""
+        """All pages of one document through the engine at once — the caller-side half of page batching (SURVEY §8(f)
+        rows 2 and 4): pipelined over the engine's sequence slots when the model has them, else ONE batched generate."""
+        if self.use_hf and hasattr(getattr(self.model, "engine", None), "slots_prefill") and len(images) > 1:
+            return self._parse_pages_pipelined(images, filename, prompt_mode, save_dir, input_path)
         prepared = [self._prepare(im, prompt_mode, "pdf", None, False) for im in images]
         if self.use_hf:
             responses = self._inference_batch_with_hf([p[0] for p in prepared], [p[1] for p in prepared])

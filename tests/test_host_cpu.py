@@ -261,3 +261,39 @@ def test_continuous_batcher_admission_and_refill_with_a_fake_engine():
         cb.submit(req(1, 200, 4))                                            # longer than max_seq_len
     with pytest.raises(ValueError):
         cb.submit(req(1, 10, 4, 400))                                        # more patches than the ViT workspace
+
+
+def test_parse_pages_pipeline_over_engine_slots(tmp_path):
+    """DotsOCRParser.parse_pages with a model that has engine slots (stand-in engine): pages are prepared on host threads,
+    admitted in order into 3 slots, finished pages are post-processed on host threads; outputs equal the one-page path."""
+    from dots_ocr.parser import DotsOCRParser
+    from fakes import FakeSlotEngine
+    cfg = DotsConfig.tiny()
+    proc = DotsOcrProcessor(cfg)
+
+    class SlotModel:
+        config = cfg
+
+        def __init__(self):
+            def script(prompt):
+                n_img = int((prompt == cfg.image_token_id).sum())
+                cells = [{"bbox": [28, 28, 140, 56], "category": "Title", "text": f"# page with {n_img} vision tokens"}]
+                return proc.tokenizer.encode(json.dumps(cells)) + [cfg.eos_token_ids[0]]
+            self.engine = FakeSlotEngine(script, max_batch=3, max_patches=1 << 20, max_prefill_tokens=1 << 20, max_seq_len=1 << 16)
+            self.engine.set_sampling(0.7, 0.9, 1)
+
+    model = SlotModel()
+    parser = DotsOCRParser(model=model, processor=proc, output_dir=str(tmp_path), num_thread=4)
+    sizes = [(300, 200), (420, 280), (280, 280), (560, 420), (300, 200), (336, 504), (200, 300)]
+    pages = [synth_page(i, s) for i, s in enumerate(sizes)]
+    rs = parser.parse_pages(pages, "doc", "prompt_layout_all_en", str(tmp_path), input_path="doc.pdf")
+    assert [r["page_no"] for r in rs] == list(range(7)) and all(r["file_path"] == "doc.pdf" for r in rs)
+    assert model.engine.sampling[0] == 0.0                                       # greedy, like the reference's HF path
+    for r, (w, h) in zip(rs, sizes):
+        ih, iw = smart_resize(h, w)
+        assert (r["input_height"], r["input_width"]) == (ih, iw)
+        md = Path(r["md_content_path"]).read_text()
+        assert md == f"# page with {(ih // 14) * (iw // 14) // 4} vision tokens"
+        assert Path(r["layout_info_path"]).exists() and Path(r["layout_image_path"]).exists()
+    pre = [e[1] for e in model.engine.log if e[0] == "prefill"]
+    assert sum(len(p) for p in pre) == 7 and all(len(p) <= 3 for p in pre) and not model.engine.slots

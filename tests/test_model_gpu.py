@@ -336,3 +336,28 @@ def test_hf_shaped_generate_switches_to_continuous_batching_for_many_pages():
     assert a.shape[0] == 7 and torch.equal(a, b)
     assert torch.equal(a[:, :inputs["input_ids"].shape[1]], inputs["input_ids"])
     model.engine.close()
+
+
+def test_parser_pipelines_a_document_over_the_engine_slots(tmp_path):
+    """DotsOCRParser.parse_pages on the real engine (2 slots, 5 pages): host preparation, GPU preprocessing, continuous batching
+    and host post-processing overlapped; every page's output files equal those of the reference's one-page-at-a-time flow."""
+    from dots_ocr.parser import DotsOCRParser
+    from dots_ocr_amd.modeling import DotsOcrHipForCausalLM
+    from dots_ocr_amd.processing import DotsOcrProcessor
+    from dots_ocr_amd.synthetic import synth_page
+    from pathlib import Path
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    model = DotsOcrHipForCausalLM.from_random(cfg, seed=7, max_batch=2, max_seq_len=768, max_patches=2048)
+    proc = DotsOcrProcessor(cfg, engine=model.engine)
+    parser = DotsOCRParser(model=model, processor=proc, output_dir=str(tmp_path), hf_max_new_tokens=20, num_thread=4)
+    sizes = [(280, 196), (196, 196), (336, 224), (224, 308), (252, 168)]
+    pages = [synth_page(i, s) for i, s in enumerate(sizes)]
+    (tmp_path / "piped").mkdir()
+    piped = parser.parse_pages(pages, "doc", "prompt_ocr", str(tmp_path / "piped"), input_path="doc.pdf")
+    assert [r["page_no"] for r in piped] == [0, 1, 2, 3, 4]
+    (tmp_path / "single").mkdir()
+    for i, page in enumerate(pages):
+        one = parser._parse_single_image(page, "prompt_ocr", str(tmp_path / "single"), "doc", source="pdf", page_idx=i)
+        assert Path(one["md_content_path"]).read_text() == Path(piped[i]["md_content_path"]).read_text(), i
+        assert (one["input_height"], one["input_width"]) == (piped[i]["input_height"], piped[i]["input_width"])
+    model.engine.close()
