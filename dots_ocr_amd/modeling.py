@@ -21,6 +21,19 @@ from .engine import Engine
 from .weights import load_state_dict, random_state_dict
 
 
+def resolve_sampling(generation_config: dict, do_sample=None, temperature=None, top_p=None):
+    """HF semantics: explicit generate() arguments win, otherwise the checkpoint's generation_config.json decides
+    (GenerationMixin.generate merges it the same way; the reference calls generate(**inputs, max_new_tokens=...) only,
+    parser.py:110).  Returns (temperature, top_p) for the engine: temperature 0 = greedy."""
+    g = generation_config or {}
+    do_sample = g.get("do_sample", False) if do_sample is None else do_sample
+    temperature = g.get("temperature", 1.0) if temperature is None else temperature
+    top_p = g.get("top_p", 1.0) if top_p is None else top_p
+    if not do_sample or temperature is None or temperature <= 0:
+        return 0.0, 1.0
+    return float(temperature), float(min(max(top_p if top_p is not None else 1.0, 1e-6), 1.0))
+
+
 def plan_batches(patches_per_seq: Sequence[int], max_batch: int, max_patches: int):
     """Consecutive sequences -> engine batches of <= max_batch sequences and <= max_patches vision patches (ViT workspace).
     A single sequence larger than the patch budget is rejected (it cannot be split: attention spans the whole image)."""
@@ -60,7 +73,15 @@ class DotsOcrHipForCausalLM:
         cfg = DotsConfig.from_pretrained(model_path)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        return cls(cfg, load_state_dict(model_path), device=device, **kw)
+        model = cls(cfg, load_state_dict(model_path), device=device, **kw)
+        gen = model_path / "generation_config.json"
+        if gen.exists():                                   # sampling defaults of the checkpoint (HF merges them into generate())
+            import json
+            g = json.loads(gen.read_text())
+            for k in ("do_sample", "temperature", "top_p"):
+                if k in g:
+                    model.generation_config[k] = g[k]
+        return model
 
     @classmethod
     def from_random(cls, cfg: Optional[DotsConfig] = None, seed: int = 0, device: int = 0, **kw):
@@ -77,20 +98,19 @@ class DotsOcrHipForCausalLM:
 
     # ------------------------------------------------------------------ generate
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None,
-                 max_new_tokens: int = 128, do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0,
-                 seed: int = 0, eos_token_id=None, pad_token_id=None, continuous: Optional[bool] = None, **_):
-        """HF-shaped generate.  Greedy by default (do_sample=False); with do_sample=True tokens are drawn on the GPU from
-        softmax(logits / temperature) restricted to the top_p nucleus, reproducibly from `seed`.  Returns LongTensor
+                 max_new_tokens: int = 128, do_sample: Optional[bool] = None, temperature: Optional[float] = None,
+                 top_p: Optional[float] = None, seed: int = 0, eos_token_id=None, pad_token_id=None, continuous: Optional[bool] = None, **_):
+        """HF-shaped generate.  do_sample / temperature / top_p default to the checkpoint's generation_config.json (greedy when it
+        is absent); with sampling on, tokens are drawn on the GPU from softmax(logits / temperature) restricted to the top_p
+        nucleus, reproducibly from `seed`.  Returns LongTensor
         [B, T + n]: the (padded) prompt followed by the new tokens, positions after a sequence's EOS filled with pad_token_id.
 
         More sequences than engine slots (B > max_batch) run with continuous batching: a slot is refilled with the next
         sequence as soon as its page hits EOS instead of waiting for the slowest page of a static batch
         (`continuous=True/False` forces either mode; greedy results are identical)."""
         import torch
-        if do_sample and temperature > 0:
-            self.engine.set_sampling(temperature, top_p, seed)
-        else:
-            self.engine.set_sampling(0.0, 1.0, 0)
+        t_eff, p_eff = resolve_sampling(self.generation_config, do_sample, temperature, top_p)
+        self.engine.set_sampling(t_eff, p_eff, seed if t_eff > 0 else 0)
         ids = input_ids.detach().cpu().numpy()
         B, T = ids.shape
         mask = attention_mask.detach().cpu().numpy().astype(bool) if attention_mask is not None else np.ones_like(ids, bool)

@@ -168,8 +168,11 @@ class DotsOCRParser:
         (host threads).  Only this thread talks to the engine (one handle per GPU, not thread-safe)."""
         from multiprocessing.pool import ThreadPool
         from .scheduler import ContinuousBatcher, Request
+        from .modeling import resolve_sampling
         engine = self.model.engine
-        engine.set_sampling(0.0, 1.0, 0)                                         # the reference's HF path is greedy (parser.py:110)
+        # generate(**inputs, max_new_tokens=...) (parser.py:110): greedy unless the checkpoint's generation_config.json samples
+        t, p_ = resolve_sampling(getattr(self.model, "generation_config", None))
+        engine.set_sampling(t, p_, 0)
         eos = list(self.model.config.eos_token_ids)
         cb = ContinuousBatcher(engine, eos_ids=eos)
         n = len(images)

@@ -297,3 +297,13 @@ def test_parse_pages_pipeline_over_engine_slots(tmp_path):
         assert Path(r["layout_info_path"]).exists() and Path(r["layout_image_path"]).exists()
     pre = [e[1] for e in model.engine.log if e[0] == "prefill"]
     assert sum(len(p) for p in pre) == 7 and all(len(p) <= 3 for p in pre) and not model.engine.slots
+
+
+def test_generation_config_defaults_follow_hf_semantics():
+    from dots_ocr_amd.modeling import resolve_sampling
+    assert resolve_sampling({}) == (0.0, 1.0)                                            # no config: greedy
+    assert resolve_sampling({"do_sample": True, "temperature": 0.7, "top_p": 0.8}) == (0.7, 0.8)   # checkpoint default
+    assert resolve_sampling({"do_sample": True, "temperature": 0.7}, do_sample=False) == (0.0, 1.0)  # explicit argument wins
+    assert resolve_sampling({"do_sample": False}, do_sample=True, temperature=0.5) == (0.5, 1.0)
+    assert resolve_sampling({"do_sample": True, "temperature": 0.0}) == (0.0, 1.0)
+    assert resolve_sampling({}, do_sample=True, temperature=1.0, top_p=3.0) == (1.0, 1.0)
