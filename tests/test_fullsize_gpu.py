@@ -152,7 +152,7 @@ def test_full_size_model_a4_pages_deterministic_and_batch_invariant():
     from dots_ocr_amd.weights import random_state_dict
     cfg = DotsConfig()
     sd = random_state_dict(cfg, seed=0, threads=min(32, os.cpu_count() or 8))
-    eng = Engine(cfg, max_batch=2, max_seq_len=5400, max_patches=2 * N_A4 + 64, max_prefill_tokens=2 * 5200 + 64)
+    eng = Engine(cfg, max_batch=2, max_seq_len=14600, max_patches=57600 + 64, max_prefill_tokens=14600)
     eng.load_state_dict(sd)
     del sd
     feats, grids = zip(*(preprocess_image(synth_page(i, A4_200DPI)) for i in range(2)))
@@ -183,4 +183,23 @@ def test_full_size_model_a4_pages_deterministic_and_batch_invariant():
         single, _ = eng.generate(prompts2[i], lens2[i:i + 1], f, grid2[i:i + 1], max_new_tokens=6)
         assert np.array_equal(single[0], m[i]), i
         off += f.shape[0]
+
+    # the largest page the reference admits: 4500x4500 px is above MAX_PIXELS and smart_resize brings it to 3332x3332
+    # (SURVEY §8(c) known answer) -> 238 x 238 = 56 644 patches, 14 161 vision tokens, one 56 644-key attention per head
+    from dots_ocr_amd.image_utils import smart_resize
+    assert smart_resize(4500, 4500) == (3332, 3332)
+    big, gbig = preprocess_image(synth_page(30, (4500, 4500)))
+    assert big.shape == (56644, 588) and list(gbig) == [1, 238, 238]
+    pbig = synth_prompt_ids(cfg, 14161, n_text_tokens=40, seed=31)
+    lbig = np.array([len(pbig)], np.int32)
+    x, lx = eng.generate(pbig, lbig, big, np.asarray([gbig], np.int64), max_new_tokens=4)
+    y, _ = eng.generate(pbig, lbig, big, np.asarray([gbig], np.int64), max_new_tokens=4)
+    assert lx.tolist() == [4] and np.array_equal(x, y) and (x >= 0).all() and (x < cfg.vocab_size).all()
+    st = eng.stats()
+    n = 56644
+    flops = 42 * (2 * n * (4 * 1536 ** 2 + 3 * 1536 * 4224) + 4 * n * n * 1536) + 2 * n * 588 * 1536 + 2 * (n // 4) * (6144 ** 2 + 6144 * 1536)
+    assert st["vit_patches"] == n and abs(st["vit_flops"] / flops - 1) < 0.01            # SURVEY §8(d) ViT formula (~965 TFLOP)
+    from dots_ocr_amd.engine import DotsEngineError
+    with pytest.raises(DotsEngineError, match="max_patches"):                             # more patches than the ViT workspace holds
+        eng.vit_forward(np.zeros((244 * 238, 588), np.float32), np.asarray([[1, 244, 238]], np.int64))
     eng.close()
