@@ -98,6 +98,17 @@ class HFJsonTokenizer:
         from tokenizers import Tokenizer
         self.tk = Tokenizer.from_file(str(path / "tokenizer.json"))
         self.pad_token_id = cfg.pad_token_id
+        self.special_tokens_map = {}                 # bos/eos/pad strings a chat template may reference
+        for name in ("special_tokens_map.json", "tokenizer_config.json"):
+            f = path / name
+            if f.exists():
+                d = json.loads(f.read_text(encoding="utf-8"))
+                for k in ("bos_token", "eos_token", "pad_token"):
+                    v = d.get(k)
+                    if isinstance(v, dict):
+                        v = v.get("content")
+                    if isinstance(v, str) and k not in self.special_tokens_map:
+                        self.special_tokens_map[k] = v
 
     def encode(self, text: str) -> List[int]:
         return self.tk.encode(text, add_special_tokens=False).ids
@@ -120,22 +131,38 @@ def process_vision_info(messages):
     return (images or None), None
 
 
+def load_chat_template(path: Path) -> Optional[str]:
+    """The places transformers looks for a processor / tokenizer chat template, in its order of precedence."""
+    path = Path(path)
+    if (path / "chat_template.jinja").exists():
+        return (path / "chat_template.jinja").read_text(encoding="utf-8")
+    for name in ("chat_template.json", "processor_config.json", "tokenizer_config.json"):
+        f = path / name
+        if f.exists():
+            t = json.loads(f.read_text(encoding="utf-8")).get("chat_template")
+            if isinstance(t, str) and t:
+                return t
+    return None
+
+
 class DotsOcrProcessor:
     """`engine`: when a dots_ocr_amd.engine.Engine is attached, images are resized / normalised / patchified on its
     GPU (bit-identical to the host Pillow path, ~100x faster for an A4 page) and `pixel_values` comes back as a CUDA
     tensor; without it the host path of image_utils.preprocess_image is used."""
 
-    def __init__(self, cfg: DotsConfig, tokenizer=None, engine=None):
+    def __init__(self, cfg: DotsConfig, tokenizer=None, engine=None, chat_template: Optional[str] = None):
         self.cfg = cfg
         self.tokenizer = tokenizer or SyntheticByteTokenizer(cfg)
         self.engine = engine
+        self.chat_template = chat_template          # the checkpoint's Jinja template, when it ships one
+        self._compiled_template = None
 
     @classmethod
     def from_pretrained(cls, path, engine=None, **_):
         path = Path(path)
         cfg = DotsConfig.from_pretrained(path)
         tok = HFJsonTokenizer(path, cfg) if (path / "tokenizer.json").exists() else None
-        return cls(cfg, tok, engine)
+        return cls(cfg, tok, engine, load_chat_template(path))
 
     def _preprocess_on_device(self, images):
         import torch
@@ -158,7 +185,26 @@ class DotsOcrProcessor:
         return pv, grids
 
     # parser.py:93-97
+    def _render_template(self, messages, add_generation_prompt: bool) -> str:
+        """Render the checkpoint's Jinja chat template the way transformers does (sandboxed, trim/lstrip blocks,
+        `raise_exception`, the special-token variables)."""
+        if self._compiled_template is None:
+            from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+            def raise_exception(message):
+                raise ValueError(message)
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+            env.globals["raise_exception"] = raise_exception
+            self._compiled_template = env.from_string(self.chat_template)
+        special = getattr(self.tokenizer, "special_tokens_map", {}) or {}
+        return self._compiled_template.render(messages=messages, add_generation_prompt=add_generation_prompt,
+                                              bos_token=special.get("bos_token", ""), eos_token=special.get("eos_token", ""),
+                                              pad_token=special.get("pad_token", ""))
+
     def apply_chat_template(self, messages, tokenize: bool = False, add_generation_prompt: bool = True):
+        if self.chat_template:
+            text = self._render_template(messages, add_generation_prompt)
+            return self.tokenizer.encode(text) if tokenize else text
         out = []
         for msg in messages:
             role, content = msg["role"], msg["content"]

@@ -307,3 +307,30 @@ def test_generation_config_defaults_follow_hf_semantics():
     assert resolve_sampling({"do_sample": False}, do_sample=True, temperature=0.5) == (0.5, 1.0)
     assert resolve_sampling({"do_sample": True, "temperature": 0.0}) == (0.0, 1.0)
     assert resolve_sampling({}, do_sample=True, temperature=1.0, top_p=3.0) == (1.0, 1.0)
+
+
+def test_checkpoint_chat_template_is_rendered_like_transformers(tmp_path):
+    """When the checkpoint ships a Jinja chat template the processor renders it (as AutoProcessor.apply_chat_template does,
+    parser.py:93-97) instead of the built-in dots.ocr format; the two agree on the reference's message shape."""
+    from dots_ocr_amd.processing import load_chat_template
+    cfg = DotsConfig.tiny()
+    tmpl = ("{%- for m in messages %}{%- if m['role'] == 'system' %}{{ m['content'] }}{%- else %}"
+            "{{ '<|' + m['role'] + '|>' }}{%- if m['content'] is string %}{{ m['content'] }}{%- else %}"
+            "{%- for c in m['content'] %}{%- if c['type'] == 'image' %}{{ '<|img|><|imgpad|><|endofimg|>' }}"
+            "{%- elif c['type'] == 'text' %}{{ c['text'] }}{%- endif %}{%- endfor %}{%- endif %}"
+            "{{ '<|endof' + m['role'] + '|>' }}{%- endif %}{%- endfor %}"
+            "{%- if add_generation_prompt %}{{ '<|assistant|>' }}{%- endif %}")
+    (tmp_path / "chat_template.json").write_text(json.dumps({"chat_template": tmpl}))
+    assert load_chat_template(tmp_path) == tmpl
+    assert load_chat_template(tmp_path / "nope") is None
+    msgs = [{"role": "user", "content": [{"type": "image", "image": "x.png"}, {"type": "text", "text": "Parse this."}]}]
+    builtin = DotsOcrProcessor(cfg)
+    templated = DotsOcrProcessor(cfg, chat_template=tmpl)
+    want = "<|user|><|img|><|imgpad|><|endofimg|>Parse this.<|endofuser|><|assistant|>"
+    assert builtin.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True) == want
+    assert templated.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True) == want
+    assert templated.apply_chat_template(msgs, tokenize=False, add_generation_prompt=False) == want[:-len("<|assistant|>")]
+    assert templated.apply_chat_template(msgs, tokenize=True) == builtin.tokenizer.encode(want)
+    bad = DotsOcrProcessor(cfg, chat_template="{{ raise_exception('no system role') }}")
+    with pytest.raises(ValueError, match="no system role"):
+        bad.apply_chat_template(msgs)
