@@ -334,3 +334,63 @@ def test_checkpoint_chat_template_is_rendered_like_transformers(tmp_path):
     bad = DotsOcrProcessor(cfg, chat_template="{{ raise_exception('no system role') }}")
     with pytest.raises(ValueError, match="no system role"):
         bad.apply_chat_template(msgs)
+
+
+def _dp_job_pages():
+    """A mixed job (BASELINE config 4 geometry in miniature): (first prompt token, prompt length, patches, cap)."""
+    rng = np.random.default_rng(2025)
+    return [(int(10 + i), int(rng.integers(8, 40)), int(rng.choice([16, 64, 144, 400])), int(rng.integers(3, 30))) for i in range(13)]
+
+
+def _dp_run_shard(page_ids):
+    """One rank: its pages through the continuous batcher over a stand-in slot engine -> padded ids + lengths."""
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    sys.path.insert(0, str(ROOT / "tests"))
+    from fakes import FakeSlotEngine
+    job = _dp_job_pages()
+    eng = FakeSlotEngine(lambda prompt: int(prompt[0]) * 1000 + np.arange(64), max_batch=3, max_patches=500, max_prefill_tokens=96, max_seq_len=256)
+    reqs = []
+    for p in page_ids:
+        first, n_tok, patches, cap = job[p]
+        reqs.append(Request(np.full(n_tok, first, np.int32), np.zeros((patches, 4), np.float32), np.array([[1, patches // 4, 4]]), cap))
+    outs = ContinuousBatcher(eng, chunk=5).run(reqs)
+    ids = np.zeros((len(outs), 64), np.int32)
+    lens = np.zeros((len(outs),), np.int32)
+    for j, o in enumerate(outs):
+        ids[j, :len(o)], lens[j] = o, len(o)
+    return ids, lens
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dots_ocr_amd import dp as _dp
+    from test_host_cpu import _dp_job_pages, _dp_run_shard
+    costs = [_dp.page_cost(patches, cap) for (_, _, patches, cap) in _dp_job_pages()]
+    mine = _dp.shard_pages(costs, world)[rank]
+    ids, lens = _dp_run_shard(mine)
+    q.put((rank, _dp.gather_token_ids(ids, lens, page_index=mine)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_job_equals_single_rank_world_size_2_gloo():
+    """Pages sharded by cost over 2 ranks, each shard continuously batched, results gathered: every rank ends up with the
+    whole job in page order and it equals the single-rank run (result equality vs 1 GPU, any page order)."""
+    import torch.multiprocessing as mp
+    single_ids, single_lens = _dp_run_shard(list(range(len(_dp_job_pages()))))
+    want = [(p, single_ids[p, :single_lens[p]].tolist()) for p in range(len(single_lens))]
+    assert all(len(t) == min(cap, 64) and t[0] == first * 1000 for (_, t), (first, _, _, cap) in zip(want, _dp_job_pages()))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == want and got[1] == want
