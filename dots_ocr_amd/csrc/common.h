@@ -51,6 +51,20 @@ DEVI int xcd_remap(int bid, int nblk) {
     return base + idx;
 }
 
+// Phase timestamps for tools/decode_bench.hip (built with -DDOTS_TRACE only; the product build has no trace code):
+// TRACE(slot) stores the 100 MHz wall clock of lane 0 of every wave into trace[(block * 16 + wave) * 8 + slot].
+#ifdef DOTS_TRACE
+#define TRACE_DECL static __device__ unsigned long long* dots_trace_buf = nullptr;
+#define TRACE(slot)                                                                                                          \
+    do {                                                                                                                     \
+        if ((threadIdx.x & 63) == 0 && dots_trace_buf)                                                                       \
+            dots_trace_buf[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define TRACE_DECL
+#define TRACE(slot)
+#endif
+
 #define HIP_CHECK_RET(expr)                                  \
     do {                                                     \
         hipError_t _e = (expr);                              \

@@ -12,14 +12,15 @@
 //                   which is exactly the key order in which a lane holds P^T after the S^T MFMAs
 //                   (A of O^T = V^T.P^T).
 //
-// Dense layers at M = B <= 16 rows: skinny split-K GEMM on MFMA with the weight tile as the A operand,
-// weights streamed straight to VGPRs in 64-B-per-lane runs (guide: "GEMV / M<=16: neither LDS nor glds"),
-// fp32 partial slabs reduced deterministically (fixed order, no atomics) inside the next fused kernel.
+// Dense layers at M = B <= 16 rows (decode_fused.hip): skinny GEMM on MFMA with the weight tile as the A operand,
+// weights streamed straight to VGPRs (guide: "GEMV / M<=16: neither LDS nor glds"), split-K only across the waves of
+// one workgroup, reduced through LDS in a fixed order.
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
 
 namespace {
+TRACE_DECL
 
 // ------------------------------------------------------------------------------------------------
 // prefill -> pages.  grid (tiles, Hkv, 2); K from the rope'd head-major buffer, V from the qkv buffer.
@@ -70,46 +71,11 @@ __global__ __launch_bounds__(256) void kv_to_pages_kernel(const bf16_t* __restri
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Skinny GEMM: partial[s][m][n] = sum over K-slice s of X[m][k] * W[n][k], m < 16, operands in
-// fragment order.  grid (ceil(N/64), S); wave = one 16-row weight tile streaming its K-slice straight
-// into the MFMA A operand, 8 chunks (8 KiB) in flight per wave, non-temporal (each byte is read once).
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ Xf, const bf16_t* __restrict__ Wd,
-                                                          float* __restrict__ partial, int N, int K, int S, int M) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = l & 15, g = l >> 4;
-    const int n_tile = blockIdx.x * 4 + w;
-    const int n0 = n_tile * 16;
-    if (n0 >= N) return;
-    const int KS = K / 32;
-    const int s = blockIdx.y;
-    const int k0 = (int)((int64_t)s * KS / S), k1 = (int)((int64_t)(s + 1) * KS / S);
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + l;
-    const bf16x8* xp = reinterpret_cast<const bf16x8*>(Xf) + l;
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    // groups of up to 8 chunks; the (wave-uniform) predicates keep a ragged tail fully pipelined:
-    // all of a group's loads are in flight before its first MFMA
-    for (int ks = k0; ks < k1; ks += 8) {
-        bf16x8 a[8], b[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ks + j < k1) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ks + j < k1) b[j] = xp[(size_t)(ks + j) * 64];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            if (ks + j < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
-            if (ks + j + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], b[j + 1], acc1, 0, 0, 0);
-        }
-    }
-    // D[n = 4g + r][m = i]  ->  partial[s][m][n0 + 4g .. +3]
-    f32x4 r = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
-    if (i < M) *reinterpret_cast<f32x4*>(partial + ((size_t)s * 16 + i) * N + n0 + 4 * g) = r;     // padding rows are never stored
-}
-
-// row-major [rows, K] -> fragment order (weights: rows = N, 16-row tiles; inputs: one 16-row tile)
-__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K) {
+// row-major [rows, K] -> fragment order (weights: rows = N, 16-row tiles; inputs: one 16-row tile).
+// The first rot_rows rows (the q and k heads of a fused qkv matrix, 128 rows per head) are additionally PERMUTED inside
+// their head so that every 16-row tile holds complete RoPE pairs (decode_fused.hip, dec_qkv): destination row 16j + t of
+// a head is source feature 8j + (t >> 1) + 64 (t & 1).
+__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int rot_rows) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;          // destination 16-B chunk
     const int KS = K / 32;
     const int64_t tiles = (rows + 15) / 16;
@@ -118,19 +84,23 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict
     const int64_t t = c >> 6;
     const int ks = (int)(t % KS);
     const int64_t tile = t / KS;
-    const int64_t row = tile * 16 + (lane & 15);
+    int64_t row = tile * 16 + (lane & 15);
+    if (row < rot_rows) {
+        const int rr = (int)(row & 127), jj = rr >> 4, tt = rr & 15;
+        row = (row & ~(int64_t)127) + 8 * jj + (tt >> 1) + 64 * (tt & 1);
+    }
     u32x4 v = {0, 0, 0, 0};
     if (row < rows) v = *reinterpret_cast<const u32x4*>(src + row * K + ks * 32 + (lane >> 4) * 8);
     *reinterpret_cast<u32x4*>(dst + c * 8) = v;
 }
 
-__global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                  int N, int S) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)16 * N) return;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += partial[(size_t)s * 16 * N + idx];
-    out[idx] = a;
+// row-major [rows, K] <-> X image [K/8][XR][8]   (parity-test entry points)
+__global__ __launch_bounds__(256) void convert_x_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int XR, int to_image) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * K) return;
+    const int m = idx / K, k = idx % K;
+    if (to_image) dst[xfrag_off(m, k, XR)] = src[idx];
+    else dst[idx] = src[xfrag_off(m, k, XR)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,6 +110,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_plain_kernel(const float* _
 // n_splits is an engine constant (from max_seq_len), so which pages a split sums — and with it every bit of the
 // result — depends on the sequence's own context only, not on what else is in the batch or on the schedule.
 // Splits past the context's last page exit at once and are not read by the combine kernel.
+// Memory round trips: {context length, first page id, q} in one, then the page itself (32 KiB per wave in flight).
 __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
                                                           const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
                                                           int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -149,25 +120,31 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
     const int group = Hq / Hkv;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
+    const int p0 = split * 4 + w;
+    TRACE(0);
     const int ctx = ctx_len[b] + 1;                       // includes the token appended this step
+    int page = block_table[b * max_pages + min(p0, max_pages - 1)];
+    // Q fragments (B operand): lane (j = i, g) holds Q[hkv*group + j][32kk + 8g .. +7]; zero rows j >= group
+    u32x4 qraw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qraw[kk] = *reinterpret_cast<const u32x4*>(q + ((size_t)b * Hq + hkv * group + min(i, group - 1)) * 128 + kk * 32 + g * 8);
     const int n_pages = (ctx + PAGE - 1) / PAGE;
     if (split * 4 >= n_pages) return;
-
-    // Q fragments (B operand): lane (j = i, g) holds Q[hkv*group + j][32kk + 8g .. +7]; zero rows j >= group
+    TRACE(1);
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        u32x4 z = {0, 0, 0, 0};
-        if (i < group) z = *reinterpret_cast<const u32x4*>(q + ((size_t)b * Hq + hkv * group + i) * 128 + kk * 32 + g * 8);
-        qf[kk] = __builtin_bit_cast(bf16x8, z);
+        const u32x4 z = {0, 0, 0, 0};
+        qf[kk] = __builtin_bit_cast(bf16x8, i < group ? qraw[kk] : z);
     }
     f32x4 o[8];
 #pragma unroll
     for (int dg = 0; dg < 8; ++dg) o[dg] = f32x4{0, 0, 0, 0};
     float m_run = -1e30f, l_run = 0.f;
 
-    for (int p = split * 4 + w; p < n_pages; p += 4 * n_splits) {
-        const int page = block_table[b * max_pages + p];
+    for (int p = p0; p < n_pages; p += 4 * n_splits) {
+        if (p != p0) page = block_table[b * max_pages + p];
         const bf16_t* kp = pool + ((size_t)(page * Hkv + hkv) * 2) * PAGE_ELEMS;
         const bf16_t* vp = kp + PAGE_ELEMS;
         bf16x8 kf[16], vf[16];
@@ -218,14 +195,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
         }
         l_run = l_run * alpha + psum;
 #pragma unroll
-        for (int dg = 0; dg < 8; ++dg) {
+        for (int dg = 0; dg < 8; ++dg)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[dg][r] *= alpha;
+        // V chunks arrive in order (slab 0: dg 0..7, then slab 1): consume them in that order
 #pragma unroll
-            for (int slab = 0; slab < 2; ++slab)
+        for (int slab = 0; slab < 2; ++slab)
+#pragma unroll
+            for (int dg = 0; dg < 8; ++dg)
                 o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[slab * 8 + dg], pf[slab], o[dg], 0, 0, 0);
-        }
     }
+    TRACE(2);
     // wave partial: l over the 4 lane groups that share a q column
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
@@ -235,6 +215,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds_o[w][i * 128 + dg * 16 + 4 * g + r] = o[dg][r];     // O^T[d = 16dg+4g+r][q = i]
     __syncthreads();
+    TRACE(3);
     // combine the 4 waves: thread -> (q head j, d) pairs
     for (int item = threadIdx.x; item < group * 128; item += 256) {
         const int j = item >> 7, d = item & 127;
@@ -250,23 +231,33 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
         part_o[base * 128 + d] = acc;
         if (d == 0) { part_ml[base * 2] = m; part_ml[base * 2 + 1] = lsum; }
     }
+    TRACE(4);
 }
 
 // out[b][head*128 + d] = sum_s w_s O_s / sum_s w_s l_s   (grid (Hq, B), block 128).
-// The split weights are computed once by the first wave (lane = split), kept in LDS; the per-feature
-// accumulation then issues its n_splits loads independently (unrolled by 4), not as a dependent chain.
+// ONE memory round trip: the context length, the (m, l) pairs and the first CMB_BATCH partial rows are all requested
+// up front, unconditionally (slots of splits without pages hold stale data and are masked with a select, never
+// multiplied); the split weights are computed by the first wave (lane = split) while the partial rows are in flight.
+constexpr int CMB_BATCH = 32;
+
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                   const int32_t* __restrict__ ctx_len, bf16_t* __restrict__ out, int Hq,
-                                                                  int Hkv, int n_splits) {
+                                                                  int Hkv, int n_splits, int XR) {
     __shared__ float wts[64];
     __shared__ float inv_l;
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const int n_used = min(n_splits, ((ctx_len[b] + 1 + PAGE - 1) / PAGE + 3) / 4);       // splits that own at least one page
     const int group = Hq / Hkv, hkv = head / group, j = head % group;
     const size_t base0 = (((size_t)b * Hkv + hkv) * n_splits) * group + j;     // + s*group
+    const int ctx = ctx_len[b];
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (base0 + (size_t)min(d, n_splits - 1) * group) * 2);
+    const float* po = part_o + base0 * 128 + d;
+    const size_t stride = (size_t)group * 128;
+    float pv[CMB_BATCH];
+#pragma unroll
+    for (int s = 0; s < CMB_BATCH; ++s) pv[s] = po[(size_t)min(s, n_splits - 1) * stride];
+    const int n_used = min(n_splits, ((ctx + 1 + PAGE - 1) / PAGE + 3) / 4);       // splits that own at least one page
     if (d < 64) {
-        float m = -1e30f, l = 0.f;
-        if (d < n_used) { m = part_ml[(base0 + (size_t)d * group) * 2]; l = part_ml[(base0 + (size_t)d * group) * 2 + 1]; }
+        const float m = d < n_used ? ml.x : -1e30f, l = d < n_used ? ml.y : 0.f;
         const float mg = wave_max(m);
         const float f = d < n_used ? __builtin_amdgcn_exp2f(m - mg) : 0.f;
         wts[d] = f;
@@ -274,18 +265,11 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
         if (d == 0) inv_l = 1.0f / lsum;
     }
     __syncthreads();
-    const float* po = part_o + base0 * 128 + d;
-    const size_t stride = (size_t)group * 128;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= n_used; s += 4) {
-        a0 += po[(size_t)s * stride] * wts[s];
-        a1 += po[(size_t)(s + 1) * stride] * wts[s + 1];
-        a2 += po[(size_t)(s + 2) * stride] * wts[s + 2];
-        a3 += po[(size_t)(s + 3) * stride] * wts[s + 3];
-    }
-    for (; s < n_used; ++s) a0 += po[(size_t)s * stride] * wts[s];
-    out[frag_off(b, head * 128 + d)] = f2bf(((a0 + a1) + (a2 + a3)) * inv_l);     // fragment-order input of the o projection
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < CMB_BATCH; ++s) acc += s < n_used ? pv[s] * wts[s] : 0.f;      // fixed order: deterministic
+    for (int s = CMB_BATCH; s < n_used; ++s) acc += po[(size_t)s * stride] * wts[s];
+    out[xfrag_off(b, head * 128 + d, XR)] = f2bf(acc * inv_l);     // X image: the input of the o projection
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,6 +425,10 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_step_kernel(const float
 
 }  // namespace
 
+#ifdef DOTS_TRACE
+void dots_trace_set_decode(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(dots_trace_buf), &buf, sizeof(buf)); }
+#endif
+
 hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
                               const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv) {
     if (n_tiles <= 0) return hipSuccess;
@@ -449,21 +437,30 @@ hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv,
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk) {
-    if (N % 16 != 0 || K % 32 != 0 || splitk < 1 || splitk > K / 32 || M < 1 || M > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((N + 63) / 64, splitk), dim3(256), 0, s, Xf, Wd, partial, N, K, splitk, M);
-    return hipGetLastError();
-}
-
 hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K) {
     if (K % 32 != 0) return hipErrorInvalidValue;
     const int64_t chunks = (rows + 15) / 16 * (K / 32) * 64;
-    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, src, dst, (int)rows, K);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, src, dst, (int)rows, K, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk) {
-    hipLaunchKernelGGL(skinny_reduce_plain_kernel, dim3((16 * N + 255) / 256), dim3(256), 0, s, partial, out, N, splitk);
+hipError_t launch_pack_frag_qkv(hipStream_t s, const bf16_t* src, bf16_t* dst, int Hq, int Hkv, int K) {
+    if (K % 32 != 0) return hipErrorInvalidValue;
+    const int rows = (Hq + 2 * Hkv) * 128;
+    const int64_t chunks = (int64_t)(rows / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, src, dst, rows, K, (Hq + Hkv) * 128);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_x(hipStream_t s, const bf16_t* src, bf16_t* x, int rows, int K) {
+    if (K % 8 != 0 || rows < 1 || rows > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(convert_x_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, s, src, x, rows, K, rows <= 8 ? 8 : 16, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows, int K) {
+    if (K % 8 != 0 || rows < 1 || rows > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(convert_x_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, s, x, dst, rows, K, rows <= 8 ? 8 : 16, 0);
     return hipGetLastError();
 }
 
@@ -478,7 +475,7 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
 
 hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, const int32_t* ctx_len, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits) {
-    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, ctx_len, out, Hq, Hkv, n_splits);
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, ctx_len, out, Hq, Hkv, n_splits, B <= 8 ? 8 : 16);
     return hipGetLastError();
 }
 

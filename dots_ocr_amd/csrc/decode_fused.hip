@@ -1,125 +1,143 @@
-// Fused dense kernels of the decode step: 6 launches per layer instead of 9.
-//
-// Round-1 profile of the first decode design (split-K slabs + separate reduce/norm/rope kernels) showed the
-// step bound by dependent-launch latency, not HBM: ~4.4 us per tiny kernel x 5 tiny kernels per layer.
-// Here every reduction stays inside a workgroup and every row-wise op rides in a GEMM prologue/epilogue:
+// Fused dense kernels of the decode step: 4 dense launches per layer.
 //
 //   dec_qkv      rmsnorm(h) prologue -> qkv GEMM -> bias + RoPE + q store + K/V page append epilogue
 //   (decode_attn + combine: decode.hip)
-//   dec_proj     o_proj / down_proj GEMM -> h += result                       (residual epilogue, no norm)
-//   dec_gateup   rmsnorm(h) prologue -> gate/up GEMM -> SwiGLU epilogue -> fragment-order activations
+//   dec_proj     o_proj / down_proj GEMM -> h += result                       (residual epilogue in place, no norm)
+//   dec_gateup   rmsnorm(h) prologue -> gate/up GEMM -> SwiGLU epilogue -> activations in the X image layout
 //   dec_lmhead   rmsnorm(h) prologue -> lm_head GEMM -> fp32 logits
 //
-// The consumer of a residual-stream row recomputes its RMS statistic itself (8 rows x 3 KB from L2, one wave
-// per row) and writes the normalised rows in MFMA fragment order into LDS, from where every wave takes its B
-// operand with one ds_read_b128 per MFMA; numerics are identical to the standalone norm kernel
-// (bf16(bf16(x*rstd)*w)).  Weights stream from HBM in fragment order straight into the A operand (decode.hip).
-// Split-K happens across the waves of ONE workgroup (up to 16) and is reduced through LDS in a fixed order:
-// deterministic, no slabs in HBM, no atomics.  N = 1536 projections run as 96 workgroups x 16 waves: a CU with
-// 16 waves x 8 KiB in flight sustains its share of HBM bandwidth.
+// What bounds these kernels (tools/bw_probe.hip, tools/decode_bench.hip on MI355X; profiles/r02_*): a dependent kernel
+// boundary is 1.6 us; a pure HBM stream of the layer's matrices takes 2.7 / 2.9 / 6-7 / 9.7-10.5 us (o, qkv, down,
+// gate|up) including that boundary; ONE workgroup pulls at most ~59 GB/s, 256 of them ~28 GB/s each (7.2 TB/s); a wave's
+// loads return IN ORDER and a CU's memory pipeline is shared by its waves; and the prologue's VALU work is paid once per
+// workgroup, so its instruction count times the workgroups per CU is real time.  Hence:
+//   1. all small operands first (residual rows, norm weights, positions, bias, page ids), unconditionally and in one
+//      round trip, pinned (PIN) so that the compiler cannot sink them behind the weight stream;
+//   2. then the wave's weight slice, non-temporal, straight into MFMA A-operand registers;
+//   3. prologue math (packed fp32 multiplies, v_cvt_pk roundings; only the waves that own a row) while the weights
+//      are in flight; normalised rows go to LDS in the X image layout (decode_layout.h);
+//   4. MFMAs as the weights land, split-K across the 4-16 waves of ONE workgroup reduced through LDS in a fixed order
+//      (deterministic, no atomics, no slabs in HBM), epilogue by one wave whose operands were fetched in step 1.
+// N = 1536 / 2048 outputs would be only 96 / 128 sixteen-row tiles, so the projections run one EIGHT-row half tile per
+// workgroup (192 / 256 workgroups): the 8 rows of a half are four whole 128-B lines of every 1 KiB fragment chunk, the
+// other 8 A-operand rows are fed duplicates and their results ignored (MFMA time is irrelevant here).  No K split across
+// workgroups anywhere: every output element is complete inside one workgroup, the residual add happens in place.
+// The consumer of a residual-stream row recomputes its RMS statistic itself; numerics are identical to the standalone
+// norm kernel (bf16(bf16(x*rstd)*w)).
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
 
 namespace {
+TRACE_DECL
 
-// Residual-stream row as the consumer sees it:  x = bf16(h[r] + sum_s slab[s][r])  (n_slabs may be 0), then
-// X = rmsnorm(x) * w for rows r < B, written to LDS in fragment order; workgroup 0 also stores x to h_out (the
-// producer of the slabs — a K-split projection — leaves the residual add to its consumer; h_out != h, ping-pong).
-// LDS image: [K/8][XR][8] with XR = 8 (B <= 8: lanes m >= 8 alias rows m-8, half the LDS, twice the occupancy) or 16.
-// Rows >= B are left untouched: column m of the MFMA result depends only on row m of X and columns >= B are never stored.
-DEVI void norm_rows_to_lds(const bf16_t* __restrict__ h, const float* __restrict__ slabs, int n_slabs, bf16_t* __restrict__ h_out,
-                           const bf16_t* __restrict__ w, int B, int dim, float eps,
-                           bf16_t* __restrict__ xs, int XR, int wave, int n_waves, int lane) {
-    for (int r = wave; r < B; r += n_waves) {
-        const bf16_t* row = h + (size_t)r * dim;
-        u32x4 v[4];
-        float ss = 0.f;
+// NC = 16-B chunks per lane per residual row: hidden size <= 512 NC.  The rows stay in registers while the weight stream is
+// in flight and the 1024-thread kernels have 128 VGPRs per lane; dots.ocr has 1536 = 512 * 3.
+constexpr int NC_MAX = 3;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+DEVI int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }       // provably wave-uniform: scalar branches, SGPR slices
+
+// PIN: an empty asm that consumes a loaded value.  It keeps LLVM from sinking the load into the (conditional) block of
+// its first real use — i.e. from re-ordering it behind the weight stream — at the price of a wait at the pin, so pins sit
+// where the value's loads have to be back anyway (in front of the norm prologue / in front of the first barrier).
+#define PIN(x) asm volatile("" ::"v"(x))
+
+// ---- residual-stream rows --------------------------------------------------------------------------------------------
+// Wave `wave` owns rows wave, wave + n_waves, ... (MAXR of them); rows >= B are clamped to B - 1 for the LOADS (every load
+// is unconditional: a branch around a load makes hipcc drain the whole memory queue at the join, guide §5 trap (c)) and
+// skipped for the math.  X = rmsnorm(x) * w goes to LDS as the X image [K/8][XR][8].
+// Rows >= B of the image are left untouched: column m of the MFMA result depends only on row m of X and columns >= B are never stored.
+template <int MAXR, int NC>
+struct Rows {
+    u32x4 v[MAXR][NC];
+    u32x4 w[NC];
+};
+
+template <int MAXR, int NC>
+DEVI void rows_issue(Rows<MAXR, NC>& R, const bf16_t* __restrict__ h, const bf16_t* __restrict__ w, int B, int dim, int wave, int n_waves, int lane) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = c * 512 + lane * 8;
-            if (k < dim) {
-                v[c] = *reinterpret_cast<const u32x4*>(row + k);
-                if (n_slabs > 0) {
-                    float f[8];
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = min(wave + i * n_waves, B - 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { f[2 * e] = lo_bf(v[c][e]); f[2 * e + 1] = hi_bf(v[c][e]); }
-                    float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int sidx = 0; sidx < n_slabs; ++sidx) {
-                        const float* sp = slabs + ((size_t)sidx * 16 + r) * dim + k;
-                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        for (int c = 0; c < NC; ++c) R.v[i][c] = *reinterpret_cast<const u32x4*>(h + (size_t)r * dim + min(c * 512 + lane * 8, dim - 8));
+    }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { add[e] += s0[e]; add[4 + e] += s1[e]; }
-                    }
+    for (int c = 0; c < NC; ++c) R.w[c] = *reinterpret_cast<const u32x4*>(w + min(c * 512 + lane * 8, dim - 8));
+}
+
+template <int MAXR, int NC>
+DEVI void pin_rows(const Rows<MAXR, NC>& R) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[c][e] = pack_bf2(f[2 * e] + add[2 * e], f[2 * e + 1] + add[2 * e + 1]);
-                    if (blockIdx.x == 0) *reinterpret_cast<u32x4*>(h_out + (size_t)r * dim + k) = v[c];
-                }
+    for (int i = 0; i < MAXR; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float a = lo_bf(v[c][e]), b = hi_bf(v[c][e]); ss += a * a + b * b; }
-            }
+        for (int c = 0; c < NC; ++c) PIN(R.v[i][c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) PIN(R.w[c]);
+}
+
+// one row -> rmsnorm -> LDS image; ~12 VALU per bf16 pair (packed fp32 multiplies, v_cvt_pk_bf16_f32 roundings)
+template <int NC>
+DEVI void row_norm_to_lds(const u32x4 (&v)[NC], const u32x4 (&w)[NC], int r, int dim, float eps, bf16_t* __restrict__ xs, int XR, int lane) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float pc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {       // (v_dot2c_f32_bf16 was tried for the statistic: its result failed the oracle comparison by ~3 %)
+            const float a = lo_bf(v[c][e]), b = hi_bf(v[c][e]);
+            pc += a * a + b * b;
         }
-        const float rstd = rsqrtf(wave_sum(ss) / dim + eps);
+        ss += (c * 512 + lane * 8 < dim) ? pc : 0.f;              // clamped (repeated) chunks past the row end do not count
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / dim + eps);
+    const f32x2 rs2 = {rstd, rstd};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = c * 512 + lane * 8;
-            if (k < dim) {
-                const u32x4 ww = *reinterpret_cast<const u32x4*>(w + k);
-                u32x4 o;
+    for (int c = 0; c < NC; ++c) {
+        const int k = c * 512 + lane * 8;
+        u32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = pack_bf2(bf2f(f2bf(lo_bf(v[c][e]) * rstd)) * lo_bf(ww[e]), bf2f(f2bf(hi_bf(v[c][e]) * rstd)) * hi_bf(ww[e]));
-                *reinterpret_cast<u32x4*>(xs + ((size_t)(k >> 3) * XR + r) * 8) = o;      // [k/8][XR rows][8]
-            }
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 x = f32x2{lo_bf(v[c][e]), hi_bf(v[c][e])} * rs2;
+            const uint32_t t = pack_bf2(x[0], x[1]);                   // modeling_qwen2.py:246-252: normalise in fp32, cast, then * weight
+            const f32x2 y = f32x2{lo_bf(t), hi_bf(t)} * f32x2{lo_bf(w[c][e]), hi_bf(w[c][e])};
+            o[e] = pack_bf2(y[0], y[1]);
         }
+        if (k < dim) *reinterpret_cast<u32x4*>(xs + ((size_t)(k >> 3) * XR + r) * 8) = o;
     }
 }
 
-// First group of (up to 8) weight chunks of a wave's K-slice: issued BEFORE the norm prologue so HBM latency runs under it.
-DEVI void preload_group(const bf16x8* __restrict__ wp, int k0, int k1, bf16x8 (&a)[8]) {
+template <int MAXR, int NC>
+DEVI void rows_norm_to_lds(const Rows<MAXR, NC>& R, int B, int dim, float eps, bf16_t* __restrict__ xs, int XR, int wave, int n_waves, int lane) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        if (k0 + j < k1) a[j] = __builtin_nontemporal_load(wp + (size_t)(k0 + j) * 64);
-}
-
-// acc = W-tile[k0..k1) . X, A from global (fragment order, non-temporal; first group already in `a`), B from LDS or
-// global (fragment order).  The next group's weight loads are issued before this group's MFMAs.
-DEVI f32x4 stream_tile(const bf16x8* __restrict__ wp, const bf16x8* xp, int xstride, int k0, int k1, bf16x8 (&a)[8]) {
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int ks = k0; ks < k1; ks += 8) {
-        bf16x8 b[8], an[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ks + j < k1) b[j] = xp[(size_t)(ks + j) * xstride];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ks + 8 + j < k1) an[j] = __builtin_nontemporal_load(wp + (size_t)(ks + 8 + j) * 64);
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            if (ks + j < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[j], acc0, 0, 0, 0);
-            if (ks + j + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], b[j + 1], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = an[j];
+    for (int i = 0; i < MAXR; ++i) {
+        const int r = wave + i * n_waves;                              // wave-uniform
+        if (r < B) row_norm_to_lds<NC>(R.v[i], R.w, r, dim, eps, xs, XR, lane);
     }
-    return acc0 + acc1;
 }
 
-// Same contraction for slices of <= 8 k-steps per round WITHOUT the next-group prefetch registers (the 16-wave qkv
-// workgroup is capped at 128 VGPRs; its slices are 6 k-steps at H = 1536, so one round is the whole slice).
-DEVI f32x4 stream_tile_lean(const bf16x8* __restrict__ wp, const bf16x8* xp, int xstride, int k0, int k1, bf16x8 (&a)[8]) {
+// ---- weight slices ---------------------------------------------------------------------------------------------------
+// The wave's slice [k0, min(k0 + G, k1)) of one tile / half tile, 1 KiB chunk per k-step, non-temporal (each byte is read
+// once).  Every load is unconditional: the slots of a slice shorter than G read a chunk of zeros instead (pointer select on a
+// wave-uniform condition), so nothing has to be masked afterwards and a full slice costs no extra traffic.
+__device__ u32x4 g_zero_chunk[64];          // zero-initialised, one 1 KiB MFMA operand
+
+template <int G>
+DEVI void weights_issue(bf16x8 (&a)[G], const bf16x8* __restrict__ wp, int k0, int k1, int lane) {
+    const bf16x8* z = reinterpret_cast<const bf16x8*>(g_zero_chunk) + lane;
+#pragma unroll
+    for (int j = 0; j < G; ++j) a[j] = __builtin_nontemporal_load(k0 + j < k1 ? wp + (size_t)(k0 + j) * 64 : z);
+}
+
+// acc = W-tile[k0 .. k0+G) . X with X from the LDS image (xp = this lane's B-operand base, stride in bf16x8 units, KS rows)
+template <int G>
+DEVI f32x4 mfma_lds(const bf16x8 (&a)[G], const bf16x8* xp, int xstride, int k0, int KS) {
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int ks = k0; ks < k1; ks += 8) {
-        if (ks != k0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (ks + j < k1) a[j] = __builtin_nontemporal_load(wp + (size_t)(ks + j) * 64);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            if (ks + j < k1) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], xp[(size_t)(ks + j) * xstride], acc0, 0, 0, 0);
-            if (ks + j + 1 < k1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], xp[(size_t)(ks + j + 1) * xstride], acc1, 0, 0, 0);
-        }
+    for (int j = 0; j < G; j += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], xp[(size_t)min(k0 + j, KS - 1) * xstride], acc0, 0, 0, 0);
+        if (j + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], xp[(size_t)min(k0 + j + 1, KS - 1) * xstride], acc1, 0, 0, 0);
     }
     return acc0 + acc1;
 }
@@ -134,10 +152,14 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// grid = (Hq + 2 Hkv) * 4 workgroups of 16 waves.  Workgroup (head, t): weight tiles (8*head + t) and (8*head + t + 4),
-// i.e. features d in [16t, 16t+16) and their RoPE partners d + 64; wave = (tile, one of 8 K-slices).
-__global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict__ h, const float* __restrict__ slabs, int n_slabs,
-                                                       bf16_t* __restrict__ h_out, const bf16_t* __restrict__ ln_w,
+// grid = (Hq + 2 Hkv) * 16 workgroups (one 8-row HALF tile each: 256 at dots.ocr's 12 + 2 + 2 heads) x 16 waves (K-slices).
+// The rows of a q / k head are stored PERMUTED (launch_pack_frag_qkv): tile j of a head holds features 8j .. 8j+7
+// interleaved with their RoPE partners, row 2a = feature 8j + a, row 2a + 1 = feature 8j + a + 64, so a lane's 4 accumulator
+// rows are two complete rotation pairs and the epilogue needs no exchange.  v heads keep the natural order.  Wave 15 owns the
+// epilogue; its operands (position, page id, bias, rotation angles) are fetched / computed while waves < B normalise the rows.
+// k-steps per wave = H / 32 / 16 <= NC (the same bound as the row chunks: H <= 512 NC).
+template <int NC>
+__global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                        const bf16_t* __restrict__ Wd, const bf16_t* __restrict__ bias,
                                                        const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
                                                        const int32_t* __restrict__ block_table, int max_pages,
@@ -146,150 +168,210 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                 // [H/8][XR][8]
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [16 waves][64 lanes]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int head = blockIdx.x >> 2, t = blockIdx.x & 3;
-    const int sel = wv & 1, slice = wv >> 1;
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int half = blockIdx.x & 1, tile = blockIdx.x >> 1, head = tile >> 3, j = tile & 7;
     const int KS = H / 32;
-    const int n_tile = head * 8 + t + 4 * sel;
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + lane;
-    const int k0 = slice * KS / 8, k1 = (slice + 1) * KS / 8;
-    bf16x8 a0[8];
-    preload_group(wp, k0, k1, a0);
-    // RoPE angles of the epilogue lanes (wave 0), computed while the first weight group is in flight: precise
-    // sincosf of a large angle takes the slow range-reduction path
-    float rc[4] = {1.f, 1.f, 1.f, 1.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (wv == 0 && (lane & 15) < B && head < Hq + Hkv) {
-        const int pos0 = ctx_len[lane & 15];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sincosf((float)pos0 * inv_freq[16 * t + 4 * (lane >> 4) + r], &rs[r], &rc[r]);
-    }
-    norm_rows_to_lds(h, slabs, n_slabs, h_out, ln_w, B, H, eps, xs, XR, wv, 16, lane);
-    __syncthreads();
-    red[wv * 64 + lane] = stream_tile_lean(wp, reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1)), 4 * XR, k0, k1, a0);
-    __syncthreads();
-    if (wv != 0) return;
-    f32x4 x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) { x1 += red[(2 * sl) * 64 + lane]; x2 += red[(2 * sl + 1) * 64 + lane]; }
+    const int k0 = wv * KS / 16, k1 = (wv + 1) * KS / 16;
     const int m = lane & 15, g = lane >> 4;
-    if (m >= B) return;
-    const int d0 = 16 * t + 4 * g;                         // this lane: features d0..d0+3 and d0+64..d0+67 of `head`
-    const int pos = ctx_len[m];
-    const int page = block_table[m * max_pages + (pos >> 6)];
-    const int key = pos & 63;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int d = d0 + r;
-        float a = x1[r], b = x2[r];
-        if (bias) { a += bf2f(bias[head * 128 + d]); b += bf2f(bias[head * 128 + d + 64]); }
-        a = bf2f(f2bf(a)); b = bf2f(f2bf(b));              // the qkv projection output is a bf16 tensor
-        if (head < Hq + Hkv) {
-            const float sn = rs[r], cs = rc[r];
-            const bf16_t o1 = f2bf(a * cs - b * sn), o2 = f2bf(b * cs + a * sn);
-            if (head < Hq) {
-                q_out[(size_t)m * Hq * 128 + head * 128 + d] = o1;
-                q_out[(size_t)m * Hq * 128 + head * 128 + d + 64] = o2;
-            } else {
-                bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
-                kp[k_chunk(key, d) * 8 + (d & 7)] = o1;
-                kp[k_chunk(key, d + 64) * 8 + (d & 7)] = o2;
-            }
-        } else {
-            bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
-            vp[v_off(key, d)] = f2bf(a);
-            vp[v_off(key, d + 64)] = f2bf(b);
-        }
+    const bool rot = head < Hq + Hkv;
+    const bool epi = wv == 15 && m < B && g < 2;         // accumulator rows 4g + r, g < 2: the 8 rows of this half
+    TRACE(0);
+    // ---- 1. small operands (one round trip)
+    Rows<1, NC> R;
+    rows_issue<1, NC>(R, h, ln_w, B, H, wv, 16, lane);
+    // accumulator rows 4g .. 4g+3 of this lane (g < 2): q / k heads (d, d + 64, d + 1, d + 65) with d = 8j + 4 half + 2g;
+    // v heads f .. f + 3 with f = 16j + 8 half + 4g
+    const int gg = g & 1;
+    const int f0 = rot ? 8 * j + 4 * half + 2 * gg : 16 * j + 8 * half + 4 * gg;          // first feature (even)
+    const int f1 = rot ? f0 + 64 : f0 + 2;                                                // second bf16 pair
+    const int mc = min(m, B - 1);
+    const int pos = ctx_len[mc];
+    const bf16_t* bp = bias ? bias + head * 128 : ln_w;           // always a valid address; masked below
+    const uint32_t bia0 = *reinterpret_cast<const uint32_t*>(bp + f0), bia1 = *reinterpret_cast<const uint32_t*>(bp + f1);
+    const float fr0 = inv_freq[f0 & 63], fr1 = inv_freq[(f0 + 1) & 63];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. weight slice: lane (g, i) reads row (i & 7) + 8 half of the chunk; rows of the other half are duplicates
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)tile * KS) * 64 + g * 16 + (m & 7) + 8 * half;
+    bf16x8 a[NC];
+    weights_issue<NC>(a, wp, k0, k1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const int page = block_table[mc * max_pages + (pos >> 6)];    // second (dependent) round trip, behind the weights
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. prologue math while the weights are in flight
+    pin_rows<1, NC>(R);
+    PIN(fr0); PIN(fr1); PIN(bia0); PIN(bia1);
+    TRACE(1);
+    float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
+    if (wv == 15 && rot) {      // precise sincosf (the fast path up to |x| < 2^17); runs beside the other waves' norm
+        sincosf((float)pos * fr0, &rs[0], &rc[0]);
+        sincosf((float)pos * fr1, &rs[1], &rc[1]);
     }
+    rows_norm_to_lds<1, NC>(R, B, H, eps, xs, XR, wv, 16, lane);
+    TRACE(2);
+    PIN(page);
+    __syncthreads();
+    TRACE(3);
+    // ---- 4. contraction
+    red[wv * 64 + lane] = mfma_lds<NC>(a, reinterpret_cast<const bf16x8*>(xs) + g * XR + (m & (XR - 1)), 4 * XR, k0, KS);
+    TRACE(4);
+    __syncthreads();
+    TRACE(5);
+    if (!epi) return;
+    f32x4 x = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) x += red[sl * 64 + lane];
+    // ---- 5. epilogue: D[row 4g + r][batch m]
+    const int key = pos & 63;
+    // bias of rows r = 0..3: rot (lo(bia0), lo(bia1), hi(bia0), hi(bia1)), else (lo(bia0), hi(bia0), lo(bia1), hi(bia1))
+    const float b0 = bias ? lo_bf(bia0) : 0.f, b1 = bias ? (rot ? lo_bf(bia1) : hi_bf(bia0)) : 0.f;
+    const float b2 = bias ? (rot ? hi_bf(bia0) : lo_bf(bia1)) : 0.f, b3 = bias ? hi_bf(bia1) : 0.f;
+    const float y[4] = {bf2f(f2bf(x[0] + b0)), bf2f(f2bf(x[1] + b1)), bf2f(f2bf(x[2] + b2)), bf2f(f2bf(x[3] + b3))};   // the qkv output is a bf16 tensor
+    if (rot) {
+        // pairs (y0, y1) = features (d, d + 64) and (y2, y3) = (d + 1, d + 65)
+        const int d = f0;
+        const uint32_t lo = pack_bf2(y[0] * rc[0] - y[1] * rs[0], y[2] * rc[1] - y[3] * rs[1]);     // features d, d + 1
+        const uint32_t hi = pack_bf2(y[1] * rc[0] + y[0] * rs[0], y[3] * rc[1] + y[2] * rs[1]);     // features d + 64, d + 65
+        if (head < Hq) {
+            bf16_t* qp = q_out + ((size_t)m * Hq + head) * 128;
+            *reinterpret_cast<uint32_t*>(qp + d) = lo;
+            *reinterpret_cast<uint32_t*>(qp + d + 64) = hi;
+        } else {
+            bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
+            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d) * 8 + (d & 7)) = lo;
+            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d + 64) * 8 + (d & 7)) = hi;
+        }
+    } else {
+        bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vp[v_off(key, f0 + r)] = f2bf(y[r]);
+    }
+    TRACE(6);
 }
 
 // ------------------------------------------------------------------------------------------------
-// o_proj / down_proj.  grid (N/16, ksplit) workgroups x 16 waves; wave = one of 16 K-slices of its workgroup's K-part.
-//   ksplit == 1 : h[m][n] += sum_k X[m][k] W[n][k]                      (residual epilogue in place)
-//   ksplit  > 1 : slab[part][m][n] = partial sum (fp32); the consumer's prologue folds h + sum(slabs) in fixed order.
-// More workgroups = more CUs streaming: a CU sustains only ~25 GB/s with 16 waves x 8 KiB in flight (round-1 profile),
-// so the 27.5 MB down projection needs > 96 of them.
-__global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ Xf, const bf16_t* __restrict__ Wd,
-                                                        bf16_t* __restrict__ h, float* __restrict__ slabs, int B, int N, int K) {
+// o_proj / down_proj:  h[m][n] += sum_k X[m][k] W[n][k]   (residual epilogue in place).
+// grid N/8 workgroups (one 8-row half tile over the FULL K) x 16 waves (K-slices); X arrives as the X image from the
+// previous kernel (L2 / Infinity Cache): its loads and the residual go first.  A slice longer than G k-steps runs in rounds
+// of G with the next round's loads issued before this round's MFMAs (down_proj at K = 8960: 17-18 k-steps per wave, G = 6).
+template <int G>
+__global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wd,
+                                                        bf16_t* __restrict__ h, int B, int N, int K, int XR) {
     __shared__ f32x4 red[16 * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_tile = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int half = blockIdx.x & 1, tile = blockIdx.x >> 1;
     const int KS = K / 32;
-    const int slice = part * 16 + wv, slices = parts * 16;
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + lane;
-    const int k0 = (int)((int64_t)slice * KS / slices), k1 = (int)((int64_t)(slice + 1) * KS / slices);
-    bf16x8 a0[8];
-    preload_group(wp, k0, k1, a0);
-    red[wv * 64 + lane] = stream_tile(wp, reinterpret_cast<const bf16x8*>(Xf) + lane, 64, k0, k1, a0);
-    __syncthreads();
-    if (wv != 0) return;
-    f32x4 a = {0, 0, 0, 0};
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) a += red[sl * 64 + lane];
+    const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);
     const int m = lane & 15, g = lane >> 4;
-    if (m >= B) return;
-    if (parts > 1) {
-        *reinterpret_cast<f32x4*>(slabs + ((size_t)part * 16 + m) * N + n_tile * 16 + 4 * g) = a;
-        return;
+    const bool epi = wv == 15 && m < B && g < 2;
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)tile * KS) * 64 + g * 16 + (m & 7) + 8 * half;
+    const bf16x8* xp = reinterpret_cast<const bf16x8*>(X) + g * XR + (m & (XR - 1));
+    const int xstride = 4 * XR;
+    bf16_t* hp = h + (size_t)min(m, B - 1) * N + tile * 16 + 8 * half + 4 * (g & 1);
+    TRACE(0);
+    const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
+    bf16x8 a[G], b[G];
+#pragma unroll
+    for (int jj = 0; jj < G; ++jj) b[jj] = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
+    __builtin_amdgcn_sched_barrier(0);
+    weights_issue<G>(a, wp, k0, k1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int ks = k0;
+    for (; ks + G < k1; ks += G) {                        // all rounds but the last
+        bf16x8 an[G], bn[G];
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) bn[jj] = xp[(size_t)min(ks + G + jj, KS - 1) * xstride];
+        weights_issue<G>(an, wp, ks + G, k1, lane);
+#pragma unroll
+        for (int jj = 0; jj < G; jj += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], b[jj], acc0, 0, 0, 0);
+            if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], b[jj + 1], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) { a[jj] = an[jj]; b[jj] = bn[jj]; }
     }
-    bf16_t* hp = h + (size_t)m * N + n_tile * 16 + 4 * g;
-    const u32x2 x = *reinterpret_cast<const u32x2*>(hp);
-    const u32x2 o = {pack_bf2(lo_bf(x[0]) + a[0], hi_bf(x[0]) + a[1]), pack_bf2(lo_bf(x[1]) + a[2], hi_bf(x[1]) + a[3])};
+#pragma unroll
+    for (int jj = 0; jj < G; jj += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], b[jj], acc0, 0, 0, 0);
+        if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], b[jj + 1], acc1, 0, 0, 0);
+    }
+    TRACE(1);
+    red[wv * 64 + lane] = acc0 + acc1;
+    PIN(res);
+    __syncthreads();
+    TRACE(2);
+    if (!epi) return;
+    f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) s += red[sl * 64 + lane];
+    const u32x2 o = {pack_bf2(lo_bf(res[0]) + s[0], hi_bf(res[0]) + s[1]), pack_bf2(lo_bf(res[1]) + s[2], hi_bf(res[1]) + s[3])};
     *reinterpret_cast<u32x2*>(hp) = o;
+    TRACE(3);
 }
 
 // ------------------------------------------------------------------------------------------------
 // act = silu(gate) * up with gate/up = rmsnorm(h) @ W13^T.  grid I/16 workgroups x GU_WAVES waves (K-slices);
 // workgroup = one (gate tile, up tile) pair of the packed W13 (64-row groups: 32 gate rows | 32 up rows).
-
 constexpr int GU_G = 12;         // k-steps per wave held in registers (H = 1536: 48 k-steps / 4 waves)
-constexpr int GU_WAVES = 4;     // 12 (single round) was measured slower: 12 waves x 49 KB LDS leaves 560 workgroups non-resident
+constexpr int GU_WAVES = 4;      // 12 (single round) was measured slower: 12 waves x 49 KB LDS leaves 560 workgroups non-resident
+#ifndef GU_EARLY_N
+#define GU_EARLY_N 4
+#endif
+constexpr int GU_EARLY = GU_EARLY_N;      // k-steps requested before the norm prologue; the rest right after it, when the row registers
+                                 // are free: all I/16 workgroups are resident only at 3 waves per SIMD, i.e. <= 168 VGPRs
 
+template <int MAXR, int NC>
 __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                                    const bf16_t* __restrict__ Wd, bf16_t* __restrict__ act,
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [GU_WAVES][2][64]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = wave_id();
     const int pair = blockIdx.x, G = pair >> 1, a = pair & 1;
     const int KS = H / 32;
-    const int k0 = wv * KS / GU_WAVES, k1 = (wv + 1) * KS / GU_WAVES;
+    const int k0 = wv * KS / GU_WAVES, k1 = (wv + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
     const int xstride = 4 * XR;
     const bf16x8* wg = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + a) * KS) * 64 + lane;
     const bf16x8* wu = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + 2 + a) * KS) * 64 + lane;
-    // the wave's WHOLE K-slice (<= GU_G k-steps x (gate, up) = 24 KiB) is in flight before (and under) the norm prologue:
-    // one HBM round trip per wave instead of three
+    TRACE(0);
+    Rows<MAXR, NC> R;
+    rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, GU_WAVES, lane);
+    __builtin_amdgcn_sched_barrier(0);
     bf16x8 a_[GU_G], u_[GU_G];
+    const bf16x8* zc = reinterpret_cast<const bf16x8*>(g_zero_chunk) + lane;
 #pragma unroll
-    for (int j = 0; j < GU_G; ++j)
-        if (k0 + j < k1) {
-            a_[j] = __builtin_nontemporal_load(wg + (size_t)(k0 + j) * 64);
-            u_[j] = __builtin_nontemporal_load(wu + (size_t)(k0 + j) * 64);
-        }
-    norm_rows_to_lds(h, nullptr, 0, nullptr, ln_w, B, H, eps, xs, XR, wv, GU_WAVES, lane);
-    __syncthreads();
-    f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
-    for (int ks = k0; ks < k1; ks += GU_G) {       // one trip when the slice fits (H <= 1536)
-#pragma unroll
-        for (int j = 0; j < GU_G; ++j)
-            if (ks + j < k1) {
-                const bf16x8 b = xp[(size_t)(ks + j) * xstride];
-                ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[j], b, ag, 0, 0, 0);
-                au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[j], b, au, 0, 0, 0);
-            }
-        if (ks + GU_G < k1) {
-#pragma unroll
-            for (int j = 0; j < GU_G; ++j)
-                if (ks + GU_G + j < k1) {
-                    a_[j] = __builtin_nontemporal_load(wg + (size_t)(ks + GU_G + j) * 64);
-                    u_[j] = __builtin_nontemporal_load(wu + (size_t)(ks + GU_G + j) * 64);
-                }
-        }
+    for (int jj = 0; jj < GU_EARLY; ++jj) {
+        a_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wg + (size_t)(k0 + jj) * 64 : zc);
+        u_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wu + (size_t)(k0 + jj) * 64 : zc);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    pin_rows<MAXR, NC>(R);
+    TRACE(1);
+    rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, GU_WAVES, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = GU_EARLY; jj < GU_G; ++jj) {
+        a_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wg + (size_t)(k0 + jj) * 64 : zc);
+        u_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wu + (size_t)(k0 + jj) * 64 : zc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE(2);
+    __syncthreads();
+    TRACE(3);
+    f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
+#pragma unroll
+    for (int jj = 0; jj < GU_G; ++jj) {
+        const bf16x8 b = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
+        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[jj], b, ag, 0, 0, 0);
+        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[jj], b, au, 0, 0, 0);
+    }
+    TRACE(4);
     red[(wv * 2) * 64 + lane] = ag;
     red[(wv * 2 + 1) * 64 + lane] = au;
     __syncthreads();
+    TRACE(5);
     const int m = lane & 15, g = lane >> 4;
     if (wv != 0 || m >= B) return;
     f32x4 gs = ag, us = au;
@@ -298,42 +380,80 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
-    store_frag4(act, m, G * 32 + a * 16 + 4 * g, o[0], o[1], o[2], o[3]);
+    store_frag4(act, m, G * 32 + a * 16 + 4 * g, XR, o[0], o[1], o[2], o[3]);
+    TRACE(6);
 }
 
 // ------------------------------------------------------------------------------------------------
-// logits[m][n] = rmsnorm(h[m]) . lm_head[n]   (fp32, never rounded).  grid ceil(V/64) workgroups x 4 waves, wave = one
-// 16-row vocabulary tile over the full K.
-__global__ __launch_bounds__(256) void dec_lmhead_kernel(const bf16_t* __restrict__ h, const float* __restrict__ slabs, int n_slabs,
-                                                         bf16_t* __restrict__ h_out, const bf16_t* __restrict__ ln_w,
-                                                         const bf16_t* __restrict__ Wd, float* __restrict__ logits,
-                                                         int B, int H, int V, float eps, int XR) {
+// logits[m][n] = rmsnorm(h[m]) . lm_head[n]   (fp32, never rounded).  grid ceil(V/256) workgroups x 16 waves, wave = one
+// 16-row vocabulary tile over the full K in rounds of LM_G k-steps (the next round's loads are issued before this round's
+// MFMAs).  16 tiles per workgroup share one norm prologue.
+constexpr int LM_G = 8;
+
+template <int NC>
+__global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
+                                                          const bf16_t* __restrict__ Wd, float* __restrict__ logits,
+                                                          int B, int H, int V, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_tile = min(blockIdx.x * 4 + wv, V / 16 - 1);          // tail waves recompute the last tile (same values)
-    const int KS = H / 32;
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int n_tile = min((int)blockIdx.x * 16 + wv, V / 16 - 1);     // tail waves recompute the last tile (same values)
+    const int KS = H / 32;                                             // a multiple of LM_G (launcher)
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + lane;
-    bf16x8 a0[8];
-    preload_group(wp, 0, KS, a0);
-    norm_rows_to_lds(h, slabs, n_slabs, h_out, ln_w, B, H, eps, xs, XR, wv, 4, lane);
+    Rows<1, NC> R;
+    rows_issue<1, NC>(R, h, ln_w, B, H, wv, 16, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a[LM_G];
+    weights_issue<LM_G>(a, wp, 0, KS, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    pin_rows<1, NC>(R);
+    rows_norm_to_lds<1, NC>(R, B, H, eps, xs, XR, wv, 16, lane);
     __syncthreads();
-    const f32x4 acc = stream_tile(wp, reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1)), 4 * XR, 0, KS, a0);
+    const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
+    const int xstride = 4 * XR;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int ks = 0;
+    for (; ks + LM_G < KS; ks += LM_G) {                 // all rounds but the last: next round's loads first
+        bf16x8 an[LM_G];
+        weights_issue<LM_G>(an, wp, ks + LM_G, KS, lane);
+#pragma unroll
+        for (int jj = 0; jj < LM_G; jj += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < LM_G; ++jj) a[jj] = an[jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < LM_G; jj += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
+    }
+    const f32x4 acc = acc0 + acc1;
     const int m = lane & 15, g = lane >> 4;
     if (m < B) *reinterpret_cast<f32x4*>(logits + (size_t)m * V + n_tile * 16 + 4 * g) = acc;
 }
 
+// Dynamic-LDS opt-in above 64 KiB, once per (kernel, device): handles of different devices may live in one process.
 template <typename Kern>
-hipError_t ensure_lds(Kern kern, size_t bytes, bool* done) {
-    if (bytes > 64 * 1024 && !*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-        *done = true;
-    }
+hipError_t ensure_lds(Kern kern, size_t bytes, uint32_t* done_mask) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint32_t bit = 1u << (dev & 31);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
     return hipSuccess;
 }
 
 }  // namespace
+
+#ifdef DOTS_TRACE
+void dots_trace_set_fused(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(dots_trace_buf), &buf, sizeof(buf)); }
+#endif
 
 hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* embed, bf16_t* h, int B, int dim) {
     if (dim % 8) return hipErrorInvalidValue;
@@ -341,48 +461,57 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
-                          const bf16_t* Wd, const bf16_t* bias,
+hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps) {
-    if (H % 256 || H > 2048) return hipErrorInvalidValue;      // 8 K-slices of whole k-steps; norm prologue covers <= 2048
-    static bool attr = false;
+    if (H % 32 || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+    static uint32_t attr = 0;
     const int XR = B <= 8 ? 8 : 16;
-    const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4);
-    hipError_t e = ensure_lds(dec_qkv_kernel, (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4), &attr);
+    const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
+    hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX>, lds_max, &attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_qkv_kernel, dim3((Hq + 2 * Hkv) * 4), dim3(1024), lds, s, h, slabs, n_slabs, h_out, ln_w, Wd, bias, inv_freq, ctx_len,
+    hipLaunchKernelGGL(dec_qkv_kernel<NC_MAX>, dim3((Hq + 2 * Hkv) * 16), dim3(1024), lds, s, h, ln_w, Wd, bias, inv_freq, ctx_len,
                        block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
     return hipGetLastError();
 }
 
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, bf16_t* h, float* slabs, int ksplit, int B, int N, int K) {
-    if (N % 16 || K % 32 || ksplit < 1 || K / 32 < 16 * ksplit || (ksplit > 1 && !slabs)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_proj_kernel, dim3(N / 16, ksplit), dim3(1024), 0, s, Xf, Wd, h, slabs, B, N, K);
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const bf16_t* Wd, bf16_t* h, int B, int N, int K) {
+    if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > 16) return hipErrorInvalidValue;
+    const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
+    const dim3 grid(N / 8);
+#define PROJ_CASE(G) hipLaunchKernelGGL(dec_proj_kernel<G>, grid, dim3(1024), 0, s, X, Wd, h, B, N, K, XR)
+    if (need <= 1) PROJ_CASE(1);
+    else if (need <= 2) PROJ_CASE(2);
+    else if (need <= 3) PROJ_CASE(3);
+    else if (need <= 4) PROJ_CASE(4);
+    else PROJ_CASE(6);
+#undef PROJ_CASE
     return hipGetLastError();
 }
 
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* W13d, bf16_t* act,
                              int B, int H, int I, float eps) {
-    if (I % 32 || H % 128 || H > 2048 || H / 32 < GU_WAVES) return hipErrorInvalidValue;
-    static bool attr = false;
+    if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > 16) return hipErrorInvalidValue;
+    static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
-    hipError_t e = ensure_lds(dec_gateup_kernel, (size_t)16 * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4), &attr);
+    const size_t lds_max = (size_t)16 * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
+    const int v = B <= 8 ? 0 : 1;
+    auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX> : dec_gateup_kernel<4, NC_MAX>;
+    hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_gateup_kernel, dim3(I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, act, B, H, I, eps, XR);
+    hipLaunchKernelGGL(kern, dim3(I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, act, B, H, I, eps, XR);
     return hipGetLastError();
 }
 
-hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
-                             const bf16_t* Wd, float* logits,
+hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, float* logits,
                              int B, int H, int V, float eps) {
-    if (V % 16 || H % 32 || H > 2048) return hipErrorInvalidValue;
-    static bool attr = false;
+    if (V % 16 || H % (32 * LM_G) || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+    static uint32_t attr = 0;
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2;
-    hipError_t e = ensure_lds(dec_lmhead_kernel, (size_t)16 * H * 2, &attr);
+    hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX>, (size_t)16 * H * 2, &attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_lmhead_kernel, dim3((V / 16 + 3) / 4), dim3(256), lds, s, h, slabs, n_slabs, h_out, ln_w, Wd, logits, B, H, V, eps, XR);
+    hipLaunchKernelGGL(dec_lmhead_kernel<NC_MAX>, dim3((V / 16 + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, logits, B, H, V, eps, XR);
     return hipGetLastError();
 }

@@ -5,17 +5,20 @@
 constexpr int PAGE = 64;
 constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
 
-// Fragment-order operand layouts of the skinny (M <= 16) GEMMs: one 1 KiB chunk per MFMA operand,
+// Operand layouts of the skinny (B <= 16 rows) GEMMs of the decode step, both in MFMA fragment order
+// (v_mfma_f32_16x16x32_bf16: lane = g*16 + i holds 8 consecutive k of row i, k-step = 32 k):
 //   weights  Wd[(n_tile*(K/32) + kstep)*64 + lane][8],  lane = g*16 + i  <->  W[16*n_tile + i][32*kstep + 8g .. +7]
-//   inputs   Xf[kstep*64 + lane][8],                     lane = g*16 + m  <->  X[m][32*kstep + 8g .. +7]
-// so every wave-level load is one contiguous, fully used 1 KiB global_load_dwordx4 (8 cache lines per
-// instruction instead of 64 quarter-used sectors with row-major operands: lm_head 2.1 -> 6.0 TB/s in round 1).
-DEVI size_t frag_off(int m, int k) { return ((size_t)((k >> 5) * 64 + ((k >> 3) & 3) * 16 + m)) * 8 + (k & 7); }
+//            one contiguous 1 KiB chunk per (tile, k-step); the two 8-row halves of a chunk are four whole 128-B lines each
+//   inputs   X[(k/8)*XR + m][8]  <->  X[m][8*(k/8) .. +7],   XR = 8 (B <= 8) or 16 rows
+//            lane (g, m) of k-step ks reads slot (4*ks + g)*XR + (m & (XR-1)): with XR = 8 lanes m and m+8 read the same 16 B,
+//            so an 8-row batch costs half the L2 traffic and half the LDS of the 16-row image.
+DEVI int xr_of(int B) { return B <= 8 ? 8 : 16; }
+DEVI size_t xfrag_off(int m, int k, int XR) { return ((size_t)(k >> 3) * XR + m) * 8 + (k & 7); }
 
-// 4 features (m, k..k+3) -> fragment-order input buffer (8-byte store)
-DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, float a, float b, float c, float d) {
+// 4 features (m, k..k+3), k % 4 == 0 -> X image (8-byte store)
+DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, int XR, float a, float b, float c, float d) {
     u32x2 pk = {pack_bf2(a, b), pack_bf2(c, d)};
-    *reinterpret_cast<u32x2*>(xf + frag_off(m, k)) = pk;
+    *reinterpret_cast<u32x2*>(xf + xfrag_off(m, k, XR)) = pk;
 }
 
 // KV page element offsets (layout in decode.hip's header)

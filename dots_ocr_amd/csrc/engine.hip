@@ -141,8 +141,8 @@ struct DotsEngine {
     float temperature = 0.f, top_p = 1.f;      // temperature <= 0: greedy (arg max)
     uint64_t seed = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
-    bf16_t *d_h = nullptr, *d_h2 = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
-    float *d_slabs = nullptr, *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
+    bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
+    float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     int B = 0;                             // sequences of the current batch
     int B_sel = 0;                         // rows the token-selection kernel runs over
     // ---- continuous batching: every sequence slot b < max_batch is free or occupied; the decode graph runs over rows
@@ -202,14 +202,6 @@ struct DotsEngine {
     } while (0)
 
 namespace {
-
-int skinny_splits(int N, int K) {
-    // aim for ~1024 workgroups (4 per CU) so every CU keeps several 8-KiB-deep weight streams in flight
-    const int blocks = (N + 63) / 64;
-    int s = (1024 + blocks / 2) / blocks;
-    s = std::max(1, std::min(s, std::min(K / 64, 16)));
-    return s;
-}
 
 // ---------------------------------------------------------------------------------- weights
 const Tensor* find(DotsEngine* e, const std::string& name) {
@@ -342,7 +334,7 @@ int finalize_weights(DotsEngine* e) {
         CK(e->alloc(&L.o_wd, (size_t)H * Nq));
         CK(e->alloc(&L.w13_wd, (size_t)2 * I * H));
         CK(e->alloc(&L.down_wd, (size_t)H * I));
-        CK(launch_pack_frag(s, L.qkv_w, L.qkv_wd, Nq + 2 * Nkv, H));
+        CK(launch_pack_frag_qkv(s, L.qkv_w, L.qkv_wd, c.num_heads, c.num_kv_heads, H));      // q / k rows permuted: whole RoPE pairs per tile
         CK(launch_pack_frag(s, L.o_w, L.o_wd, H, Nq));
         CK(launch_pack_frag(s, L.w13, L.w13_wd, 2 * I, H));
         CK(launch_pack_frag(s, L.down_w, L.down_wd, H, I));
@@ -424,8 +416,6 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->am_idx, (size_t)mb * 64));
     CK(e->alloc(&e->am_val, (size_t)mb * 64));
     CK(e->alloc(&e->d_h, (size_t)16 * H));
-    CK(e->alloc(&e->d_h2, (size_t)16 * H));
-    CK(e->alloc(&e->d_slabs, (size_t)4 * 16 * H));
     CK(e->alloc(&e->d_q, (size_t)16 * Nq));
     CK(e->alloc(&e->d_att, (size_t)16 * Nq));
     CK(e->alloc(&e->d_act, (size_t)16 * c.intermediate_size));
@@ -667,7 +657,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     }
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, slots ? e->p_dst : nullptr, e->d_h, B, H));
-    CK(launch_dec_lmhead(s, e->d_h, nullptr, 0, nullptr, e->final_norm, e->lm_head_d, e->d_logits, rows, H, c.vocab_size, c.rms_norm_eps));
+    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->d_logits, rows, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = rows;
     e->sel_now = e->d_sel_new;
     RET(select_tokens(e, 0));
@@ -700,27 +690,20 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
     const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, I = c.intermediate_size;
     const int B = e->B;
     const float scale = 1.0f / sqrtf(128.0f);
-    // residual stream ping-pong: a K-split down projection leaves "h + slabs" to its consumer's prologue, which
-    // materialises the new row in the other buffer (workgroup 0) while every workgroup reads the old one
-    bf16_t* hb[2] = {e->d_h, e->d_h2};
-    int cur = 0, n_slabs = 0;
-    const int down_split = (I / 32 >= 32) ? 2 : 1;      // 192 workgroups for the 27.5 MB down projection
-    CK(launch_dec_embed(s, e->cur_tokens, e->embed, hb[cur], B, H));
+    CK(launch_dec_embed(s, e->cur_tokens, e->embed, e->d_h, B, H));
     static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
     for (int i = 0; i < c.num_layers; ++i) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
-        CK(launch_dec_qkv(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], L.ln1, L.qkv_wd, L.qkv_b, e->lm_inv_freq, e->ctx_len,
-                          e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq, Hkv, c.rms_norm_eps));
-        if (n_slabs) cur ^= 1;
+        CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
+                          Hkv, c.rms_norm_eps));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
-        CK(launch_dec_proj(s, e->d_att, L.o_wd, hb[cur], nullptr, 1, B, H, Nq));
-        CK(launch_dec_gateup(s, hb[cur], L.ln2, L.w13_wd, e->d_act, B, H, I, c.rms_norm_eps));
-        CK(launch_dec_proj(s, e->d_act, L.down_wd, hb[cur], e->d_slabs, down_split, B, H, I));
-        n_slabs = down_split > 1 ? down_split : 0;
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, e->d_h, B, H, Nq));
+        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, e->d_act, B, H, I, c.rms_norm_eps));
+        CK(launch_dec_proj(s, e->d_act, L.down_wd, e->d_h, B, H, I));
     }
-    CK(launch_dec_lmhead(s, hb[cur], e->d_slabs, n_slabs, hb[cur ^ 1], e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
+    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = B;
     e->sel_now = e->d_sel;
     RET(select_tokens(e, 1));
@@ -740,6 +723,25 @@ double decode_step_bytes(const DotsConfig& c) {
 
 }  // namespace
 
+// scratch device buffers of the single-kernel entry points, released (after a stream sync) on scope exit
+namespace {
+struct Scratch {
+    DotsEngine* e;
+    std::vector<void*> ptrs;
+    explicit Scratch(DotsEngine* e_) : e(e_) {}
+    template <typename T>
+    hipError_t get(T** p, size_t n) {
+        hipError_t r = e->alloc(p, n);
+        if (r == hipSuccess) ptrs.push_back(*p);
+        return r;
+    }
+    ~Scratch() {
+        hipStreamSynchronize(e->stream);
+        for (void* p : ptrs) e->release(p);
+    }
+};
+}  // namespace
+
 // ===================================================================================== C ABI
 extern "C" {
 
@@ -756,7 +758,7 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
     if (c.num_heads % c.num_kv_heads || c.num_heads / c.num_kv_heads > 16) return bad("unsupported GQA group");
     if (c.hidden_size % 128 || c.v_embed_dim % 128 || c.vocab_size % 128) return bad("hidden sizes and vocab must be multiples of 128");
     if (c.intermediate_size % 64 || c.v_intermediate % 64) return bad("intermediate sizes must be multiples of 64");
-    if (c.hidden_size > 2048 || c.hidden_size % 256) return bad("hidden_size must be a multiple of 256 and <= 2048 (decode kernels)");
+    if (c.hidden_size > 1536 || c.hidden_size % 256) return bad("hidden_size must be a multiple of 256 and <= 1536 (decode kernels keep a residual row in registers)");
     if (c.num_heads * 128 < 512 || c.intermediate_size < 512) return bad("projection K too small for the 16-way in-workgroup split");
     if (c.max_batch < 1 || c.max_batch > 16) return bad("max_batch must be in [1,16]");
     if (c.max_seq_len < 64 || c.max_patches < 4 || c.max_prefill_tokens < 1) return bad("capacity fields too small");
@@ -1269,22 +1271,90 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, voi
     return DOTS_OK;
 }
 
-int dots_op_gemm_skinny(DotsEngine* e, const void* X, const void* W, void* out_f32, int M, int N, int K) {
-    if (!e || M < 1 || M > 16) return DOTS_E_INVALID;
+// ---- single decode kernels at caller-chosen dimensions (tests/test_decode_kernels_gpu.py).  Inputs are ROW-MAJOR bf16
+// tensors as the HF state dict holds them; the fragment-order / permuted packing the decode step uses happens inside, with
+// the same pack kernels the engine runs at dots_finalize_weights.
+
+int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* wqkv, const void* bias, const int32_t* ctx_len_dev,
+                    const int32_t* block_table_dev, int max_pages, void* pool_layer, void* q_out, int B, int H, int Hq, int Hkv, float eps,
+                    float rope_theta) {
+    if (!e || !h || !ln_w || !wqkv || !ctx_len_dev || !block_table_dev || !pool_layer || !q_out) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
-    const int S = skinny_splits(N, K);
-    float* partial = nullptr;
-    bf16_t *xf = nullptr, *wd = nullptr;
-    CK(e->alloc(&partial, (size_t)S * 16 * N));
-    CK(e->alloc(&xf, (size_t)16 * K));
-    CK(e->alloc(&wd, (size_t)N * K));
-    hipError_t r = launch_pack_frag(e->stream, (const bf16_t*)X, xf, 16, K);
-    if (r == hipSuccess) r = launch_pack_frag(e->stream, (const bf16_t*)W, wd, N, K);
-    if (r == hipSuccess) r = launch_gemm_skinny(e->stream, xf, wd, partial, 16, N, K, S);
-    if (r == hipSuccess) r = launch_skinny_reduce_plain(e->stream, partial, (float*)out_f32, N, S);
-    hipStreamSynchronize(e->stream);
-    e->release(partial); e->release(xf); e->release(wd);
-    CK(r);
+    Scratch sc(e);
+    bf16_t* wd = nullptr;
+    float* freq = nullptr;
+    CK(sc.get(&wd, (size_t)(Hq + 2 * Hkv) * 128 * H));
+    CK(sc.get(&freq, 64));
+    float f[64];
+    for (int i = 0; i < 64; ++i) f[i] = 1.0f / powf(rope_theta, (float)(2 * i) / 128.0f);
+    CK(hipMemcpyAsync(freq, f, sizeof(f), hipMemcpyHostToDevice, e->stream));
+    CK(launch_pack_frag_qkv(e->stream, (const bf16_t*)wqkv, wd, Hq, Hkv, H));
+    CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
+                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_op_decode_attn(DotsEngine* e, const void* q, const void* pool_layer, const int32_t* ctx_len_dev, const int32_t* block_table_dev,
+                        int max_pages, void* out, int B, int Hq, int Hkv, int max_seq_len) {
+    if (!e || !q || !pool_layer || !ctx_len_dev || !block_table_dev || !out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad decode_attn arguments") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    Scratch sc(e);
+    const int n_splits = splits_for_ctx(max_seq_len);
+    float *po = nullptr, *pml = nullptr;
+    bf16_t* att = nullptr;
+    CK(sc.get(&po, (size_t)16 * Hq * n_splits * 128));
+    CK(sc.get(&pml, (size_t)16 * Hq * n_splits * 2));
+    CK(sc.get(&att, (size_t)16 * Hq * 128));
+    CK(hipMemsetAsync(po, 0xff, (size_t)16 * Hq * n_splits * 128 * 4, e->stream));      // NaN: a partial read without having been written shows up
+    CK(hipMemsetAsync(pml, 0xff, (size_t)16 * Hq * n_splits * 2 * 4, e->stream));
+    CK(launch_decode_attn(e->stream, (const bf16_t*)q, (const bf16_t*)pool_layer, ctx_len_dev, block_table_dev, max_pages, po, pml, B, Hq, Hkv, n_splits,
+                          1.0f / sqrtf(128.0f)));
+    CK(launch_decode_attn_combine(e->stream, po, pml, ctx_len_dev, att, B, Hq, Hkv, n_splits));
+    CK(launch_unpack_x(e->stream, att, (bf16_t*)out, B, Hq * 128));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout, int B, int N, int K) {
+    if (!e || !x || !w || !h_inout || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_proj arguments") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    Scratch sc(e);
+    bf16_t *xi = nullptr, *wd = nullptr;
+    CK(sc.get(&xi, (size_t)16 * K));
+    CK(sc.get(&wd, (size_t)N * K));
+    CK(launch_pack_x(e->stream, (const bf16_t*)x, xi, B, K));
+    CK(launch_pack_frag(e->stream, (const bf16_t*)w, wd, N, K));
+    CK(launch_dec_proj(e->stream, xi, wd, (bf16_t*)h_inout, B, N, K));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const void* gate_w, const void* up_w, void* act_out, int B, int H, int I, float eps) {
+    if (!e || !h || !ln_w || !gate_w || !up_w || !act_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_gateup arguments") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    Scratch sc(e);
+    bf16_t *w13 = nullptr, *w13d = nullptr, *act = nullptr;
+    CK(sc.get(&w13, (size_t)2 * I * H));
+    CK(sc.get(&w13d, (size_t)2 * I * H));
+    CK(sc.get(&act, (size_t)16 * I));
+    CK(launch_pack_w13(e->stream, (const bf16_t*)gate_w, (const bf16_t*)up_w, w13, I, H));
+    CK(launch_pack_frag(e->stream, w13, w13d, 2 * I, H));
+    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, act, B, H, I, eps));
+    CK(launch_unpack_x(e->stream, act, (bf16_t*)act_out, B, I));
+    CK(hipStreamSynchronize(e->stream));
+    return DOTS_OK;
+}
+
+int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const void* w, void* logits_out, int B, int H, int V, float eps) {
+    if (!e || !h || !ln_w || !w || !logits_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_lmhead arguments") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    Scratch sc(e);
+    bf16_t* wd = nullptr;
+    CK(sc.get(&wd, (size_t)V * H));
+    CK(launch_pack_frag(e->stream, (const bf16_t*)w, wd, V, H));
+    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, (float*)logits_out, B, H, V, eps));
+    CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
 

@@ -42,19 +42,16 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
 // ---- decode.hip  (KV page pool layout documented there)
 hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
                               const int32_t* block_table, int max_pages, bf16_t* pool_layer, int64_t T, int Hq, int Hkv);
-hipError_t launch_gemm_skinny(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, float* partial, int M, int N, int K, int splitk);   // fragment-order operands
-hipError_t launch_skinny_reduce_plain(hipStream_t s, const float* partial, float* out, int N, int splitk);
-// ---- decode_fused.hip: dense layers of the decode step with in-workgroup split-K and fused prologues/epilogues
+// ---- decode_fused.hip: dense layers of the decode step with in-workgroup split-K and fused prologues/epilogues.
+// Activations between them travel as X images [K/8][XR][8], XR = 8 (B <= 8) or 16 (decode_layout.h).
 hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* embed, bf16_t* h, int B, int dim);
-hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
-                          const bf16_t* Wd, const bf16_t* bias,
+hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps);
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* Xf, const bf16_t* Wd, bf16_t* h, float* slabs, int ksplit, int B, int N, int K);
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const bf16_t* Wd, bf16_t* h, int B, int N, int K);       // h += X @ W^T
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* W13d, bf16_t* act,
                              int B, int H, int I, float eps);
-hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const float* slabs, int n_slabs, bf16_t* h_out, const bf16_t* ln_w,
-                             const bf16_t* Wd, float* logits,
+hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, float* logits,
                              int B, int H, int V, float eps);
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
@@ -74,6 +71,11 @@ hipError_t launch_sample_step(hipStream_t s, const float* logits, int V, int ld,
                               const StepState& st);
 // row-major [rows, K] -> MFMA fragment order (decode.hip): 16-row tiles x K/32 chunks of 1 KiB
 hipError_t launch_pack_frag(hipStream_t s, const bf16_t* src, bf16_t* dst, int64_t rows, int K);
+// fused qkv weight [(Hq + 2 Hkv) * 128, K]: as launch_pack_frag, q / k head rows permuted so that a 16-row tile holds whole RoPE pairs
+hipError_t launch_pack_frag_qkv(hipStream_t s, const bf16_t* src, bf16_t* dst, int Hq, int Hkv, int K);
+// row-major [rows <= 16, K] <-> X image [K/8][XR][8] (XR = 8 for rows <= 8, else 16): the single-kernel entry points' converters
+hipError_t launch_pack_x(hipStream_t s, const bf16_t* src, bf16_t* x, int rows, int K);
+hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows, int K);
 // ---- engine.hip helper kernels
 hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
 hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);

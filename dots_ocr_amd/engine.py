@@ -89,7 +89,11 @@ def _prototypes(lib):
         "dots_op_gemm": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]),
         "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
         "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
-        "dots_op_gemm_skinny": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32]),
+        "dots_op_decode_attn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32]),
+        "dots_op_dec_proj": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "dots_op_dec_gateup": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32]),
+        "dots_op_dec_lmhead": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32]),
         "dots_probe_mfma": (i32, [i32, vp, vp, vp, vp]),
         "dots_probe_grid_barrier": (i32, [i32, i32, i32, i32, i32, P(f32), P(i32)]),
         "dots_probe_cu_mask": (i32, [P(C.c_uint32), i32, i32, i32, i32, P(C.c_uint32)]),
@@ -107,7 +111,8 @@ EXPORTED_SYMBOLS = [
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
-    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_gemm_skinny", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
+    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
+    "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
 
 
@@ -368,5 +373,20 @@ class Engine:
         self._ck(self.lib.dots_op_qkv_rope_split(self.h, qkv, q, k, vt, _i32p(cu), cu.shape[0] - 1, _i32p(pos), Hq, Hkv,
                                                  int(rope2d), theta), "dots_op_qkv_rope_split")
 
-    def op_gemm_skinny(self, X, W, out, M, N, K):
-        self._ck(self.lib.dots_op_gemm_skinny(self.h, X, W, out, M, N, K), "dots_op_gemm_skinny")
+    # ---- single kernels of the decode step (row-major device tensors; packing happens inside the library)
+    def op_dec_qkv(self, h, ln_w, wqkv, bias, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, rope_theta):
+        self._ck(self.lib.dots_op_dec_qkv(self.h, h, ln_w, wqkv, bias or None, ctx_len, block_table, max_pages, pool_layer, q_out,
+                                          B, H, Hq, Hkv, eps, rope_theta), "dots_op_dec_qkv")
+
+    def op_decode_attn(self, q, pool_layer, ctx_len, block_table, max_pages, out, B, Hq, Hkv, max_seq_len):
+        self._ck(self.lib.dots_op_decode_attn(self.h, q, pool_layer, ctx_len, block_table, max_pages, out, B, Hq, Hkv, max_seq_len),
+                 "dots_op_decode_attn")
+
+    def op_dec_proj(self, x, w, h_inout, B, N, K):
+        self._ck(self.lib.dots_op_dec_proj(self.h, x, w, h_inout, B, N, K), "dots_op_dec_proj")
+
+    def op_dec_gateup(self, h, ln_w, gate_w, up_w, act_out, B, H, I, eps):
+        self._ck(self.lib.dots_op_dec_gateup(self.h, h, ln_w, gate_w, up_w, act_out, B, H, I, eps), "dots_op_dec_gateup")
+
+    def op_dec_lmhead(self, h, ln_w, w, logits_out, B, H, V, eps):
+        self._ck(self.lib.dots_op_dec_lmhead(self.h, h, ln_w, w, logits_out, B, H, V, eps), "dots_op_dec_lmhead")

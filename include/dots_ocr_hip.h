@@ -52,7 +52,7 @@ typedef struct DotsConfig {
     float v_rms_eps, v_ln_eps;
     int32_t v_use_bias, v_post_norm;
     /* runtime capacity */
-    int32_t max_batch;        /* sequences decoded together (<= 64) */
+    int32_t max_batch;        /* sequences decoded together (<= 16: one MFMA column tile of the decode kernels) */
     int32_t max_seq_len;      /* prompt + generated tokens per sequence */
     int64_t max_patches;      /* vision patches per dots_vit_forward call (workspace) */
     int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
@@ -189,8 +189,29 @@ int dots_op_flash_attn(DotsEngine* e, const void* q_dev, const void* k_dev, cons
 int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv_dev, void* q_dev, void* k_dev, void* vt_dev,
                            const int32_t* cu_seqlens_host, int n_seq, const int32_t* pos_host,
                            int Hq, int Hkv, int rope2d, float theta);
-/* Skinny decode GEMM: out f32 [16, N] = X[16 (M valid), K] @ W[N,K]^T  (split-K reduced). */
-int dots_op_gemm_skinny(DotsEngine* e, const void* X_dev, const void* W_dev, void* out_f32_dev, int M, int N, int K);
+/* ---- single kernels of the decode step, at caller-chosen dimensions.  All tensors are device pointers in
+ * the ROW-MAJOR layouts of the HF state dict / of a plain [B, features] activation; the MFMA fragment-order packing the
+ * decode step uses (csrc/decode_layout.h) is applied inside with the engine's own pack kernels.  B <= 16.
+ *
+ * dots_op_dec_qkv      h [B,H] -> RMSNorm(ln_w) -> fused qkv projection wqkv [(Hq+2Hkv)*128, H] + bias -> 1-D RoPE at position
+ *                      ctx_len[b] -> q_out bf16 [B, Hq*128]; the new key / value row of every sequence is appended to its
+ *                      page: pool_layer [pages][Hkv][K|V][8192] bf16 (csrc/decode.hip header), block_table int32
+ *                      [B, max_pages], ctx_len int32 [B] (tokens already in the cache).
+ * dots_op_decode_attn  q bf16 [B, Hq*128] against the paged cache holding ctx_len[b] + 1 tokens per sequence (split-KV
+ *                      kernel + combine kernel, KV split = the engine constant derived from max_seq_len) -> out bf16 [B, Hq*128].
+ * dots_op_dec_proj     h_inout [B,N] += x [B,K] @ w [N,K]^T   (o_proj / down_proj with the residual add).
+ * dots_op_dec_gateup   act_out [B,I] = silu(g) * u with g|u = RMSNorm(h) @ gate_w|up_w [I,H]^T.
+ * dots_op_dec_lmhead   logits_out fp32 [B,V] = RMSNorm(h) @ w [V,H]^T. */
+int dots_op_dec_qkv(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* wqkv_dev, const void* bias_dev,
+                    const int32_t* ctx_len_dev, const int32_t* block_table_dev, int max_pages, void* pool_layer_dev, void* q_out_dev,
+                    int B, int H, int Hq, int Hkv, float eps, float rope_theta);
+int dots_op_decode_attn(DotsEngine* e, const void* q_dev, const void* pool_layer_dev, const int32_t* ctx_len_dev,
+                        const int32_t* block_table_dev, int max_pages, void* out_dev, int B, int Hq, int Hkv, int max_seq_len);
+int dots_op_dec_proj(DotsEngine* e, const void* x_dev, const void* w_dev, void* h_inout_dev, int B, int N, int K);
+int dots_op_dec_gateup(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* gate_w_dev, const void* up_w_dev, void* act_out_dev,
+                       int B, int H, int I, float eps);
+int dots_op_dec_lmhead(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* w_dev, void* logits_out_dev, int B, int H, int V,
+                       float eps);
 
 /* MFMA fragment-layout / LDS-DMA probe (csrc/probe_mfma.hip; tests/test_mfma_layout.py). */
 int dots_probe_mfma(int which, const void* A, const void* Bt, void* D, void* stream);

@@ -242,13 +242,14 @@ def build_embeds(sd: SD, cfg, input_ids: torch.Tensor, vision_embeds: Optional[t
 def generate(sd: SD, cfg, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
              grid_thw: Optional[torch.Tensor], max_new_tokens: int, eos_ids: Tuple[int, ...] = (),
              emulate_bf16: bool = False, forced_tokens: Optional[List[int]] = None,
-             return_logits: bool = False):
+             return_logits: bool = False, vision_embeds: Optional[torch.Tensor] = None):
     """Greedy decode of ONE sequence (reference parser.py:110 with do_sample=False).
     forced_tokens: teacher forcing (feed these instead of the argmax) so per-step logits can be
     compared with an engine that took a different branch at a near-tie.
+    vision_embeds: merged vision rows computed elsewhere (skips the tower: LM-only comparisons at full context length).
     Returns (new_token_ids, [logits per step] if return_logits)."""
-    vis = None
-    if pixel_values is not None:
+    vis = vision_embeds
+    if vis is None and pixel_values is not None:
         vis = vision_tower(sd, cfg, pixel_values, grid_thw, emulate_bf16)
     emb = build_embeds(sd, cfg, input_ids, vis)
     if emulate_bf16:

@@ -220,18 +220,6 @@ def test_flash_attn_online_softmax_rescale_branch(eng):
     close(out.view(n, H, 128), ref.transpose(0, 1), rel=2 ** -6, abs_=4e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (8, 256, 768), (16, 1024, 1536), (5, 1536, 8960)])
-def test_gemm_skinny(eng, M, N, K):
-    g = torch.Generator().manual_seed(N + M)
-    X = torch.zeros(16, K)
-    X[:M] = torch.randn(M, K, generator=g)
-    X, W = bf(X), bf(torch.randn(N, K, generator=g) / math.sqrt(K))
-    Xd, Wd = dev(X), dev(W)
-    out = torch.zeros(16, N, dtype=torch.float32, device="cuda")
-    run(eng, eng.op_gemm_skinny, Xd.data_ptr(), Wd.data_ptr(), out.data_ptr(), M, N, K)
-    close(out[:M], X[:M].float() @ W.float().t(), rel=1e-4, abs_=1e-4)
-
-
 @pytest.mark.parametrize("w,h", [(1654, 2339), (333, 517), (100, 40), (1344, 1344), (3000, 4200), (28, 28)])
 def test_gpu_preprocess_is_bit_identical_to_host_pillow_path(eng, w, h):
     """uint8 page -> float32 patches on the GPU (Pillow-exact fixed-point bicubic + normalise + patchify)
