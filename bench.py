@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: pages/sec + output tok/s, dots.ocr 1.7B bf16, A4@200dpi page batch
-(BASELINE.json metric; workload = configs[1]: batch of 8 synthetic A4 pages per GPU, layout-all
-prompt shape, greedy, max_new_tokens=1024 with EOS disabled so every page emits exactly 1024 tokens).
+(BASELINE.json metric; default workload = configs[1]: batch of 8 synthetic A4 pages per GPU, layout-all
+prompt, greedy, max_new_tokens=1024 with EOS disabled so every page emits exactly 1024 tokens).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one full pass of the hot path over one batch: ViT encode + merger + LM prefill + the
-decode loop, inputs (normalised patches, token ids) already resident in HBM.  Data-parallel: one
-process per GPU, a full replica each, the page batch sharded by page, the only collective being
-the final gather of token ids (RCCL).  scaling = weak (8 pages per GPU).
+One "step" = one full pass of the hot path (reference dots_ocr/parser.py:78-117) over one batch, END TO END from the
+uint8 page pixels resident in HBM to strings on the host:
+    chat template + tokenisation (host)  ->  bicubic resize / normalise / patchify (GPU, Pillow-exact)  ->  ViT + merger
+    ->  LM prefill  ->  hipGraph'd greedy decode loop  ->  token ids to the host  ->  detokenisation.
+Data-parallel: one process per GPU, a full replica each, pages sharded by page, the only collective being the final
+gather of token ids (RCCL).  --workload a4 / highres: weak scaling (B pages per GPU).  --workload mixed64: BASELINE
+configs[3], 64 mixed-size pages for the whole job, cost-sharded (LPT) over the ranks, continuous batching per rank: strong scaling.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field contract).
 """
@@ -26,10 +29,13 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
+N_TEXT_TOKENS = 241            # BPE length of the chat template around prompt_layout_all_en (T = 4956 + ~244)
+
+# BASELINE configs[3] / SURVEY §8(d) config 4: empirical fixture distribution of page sizes (width, height), seed 2025
+MIXED_SIZES = [((1654, 2339), 0.50), ((1700, 2250), 0.15), ((2339, 3308), 0.10), ((1344, 1344), 0.10), ((946, 1024), 0.10), ((583, 550), 0.05)]
 
 
 def parse():
@@ -37,37 +43,90 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="pages per GPU per step")
+    ap.add_argument("--batch", type=int, default=8, help="pages per GPU per step (sequence slots per GPU for mixed64)")
     ap.add_argument("--max-new-tokens", type=int, default=1024)
-    ap.add_argument("--workload", default="a4", choices=["a4", "highres", "tiny"])
+    ap.add_argument("--workload", default="a4", choices=["a4", "highres", "tiny", "mixed64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd_bf16, cores):
-    """The CPU oracle (fp32 PyTorch restatement of the reference's HF path) timed on a bounded sample of
-    the same workload: ONE synthetic page at quarter linear scale, 16 greedy tokens.  Checker code used
-    only as the baseline being reported, never on the product path."""
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks (one per GPU) through torch.distributed.run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    os.execvp(cmd[0], cmd)
+
+
+def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
+    """The fp32 CPU oracle (PyTorch restatement of the reference's HF path, oracle/model.py) timed on a BOUNDED sample of the
+    SAME unit of work — one full A4 page with its 5 200-token prompt — and extrapolated exactly by layer count: every
+    ViT block costs the same, every LM layer costs the same, every decode step (at fixed context) costs the same.  Timed:
+    the tower with 0 and with 1 block, the LM prefill with 0 and with 1 layer, 4 decode steps with 0 and with 1 layer.
+    Checker code used only as the baseline being reported, never on the product path."""
+    import copy
+    import torch
     from dots_ocr_amd.image_utils import preprocess_image
-    from dots_ocr_amd.synthetic import A4_200DPI, synth_page, synth_prompt_ids
     from oracle import model as om
     torch.set_num_threads(cores)
-    sd = {k: v.float() for k, v in sd_bf16.items()}
-    page = synth_page(0, (A4_200DPI[0] // 4, A4_200DPI[1] // 4))
     pv, thw = preprocess_image(page)
-    ids = torch.from_numpy(synth_prompt_ids(cfg, thw[1] * thw[2] // 4).astype(np.int64))
-    n_new = 16
-    t0 = time.perf_counter()
-    om.generate(sd, cfg, ids, torch.from_numpy(pv), torch.tensor([thw]), n_new, emulate_bf16=False)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"1 synthetic page {page.size[0]}x{page.size[1]} px ({pv.shape[0]} patches, {len(ids)} prompt tokens), "
-                      f"{n_new} greedy tokens, full-size 1.2B ViT + 1.7B LM in fp32: {dt:.1f} s, {n_new / dt:.2f} tok/s incl. prefill"}
+    t_ids = torch.from_numpy(ids.astype(np.int64))
+    grid = torch.tensor([thw])
+    keep = lambda name: (not name.startswith("vision_tower.blocks.") or name.startswith("vision_tower.blocks.0.")) and \
+        (not name.startswith("model.layers.") or name.startswith("model.layers.0."))
+    sd = {k: v.float() for k, v in sd_bf16.items() if keep(k)}
+
+    def cfg_with(v_layers, layers):
+        c = copy.deepcopy(cfg)
+        c.vision.num_hidden_layers, c.num_hidden_layers = v_layers, layers
+        return c
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        out = fn()
+        return time.perf_counter() - t0, out
+    with torch.no_grad():
+        t_v0, _ = timed(lambda: om.vision_tower(sd, cfg_with(0, 0), torch.from_numpy(pv), grid))
+        t_v1, vis = timed(lambda: om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv), grid))
+        emb = om.build_embeds(sd, cfg, t_ids, vis)
+        n_dec = 4
+        res = {}
+        for layers in (0, 1):
+            c = cfg_with(1, layers)
+            cache = om.KVCache(max(1, layers))
+            t_p, logits = timed(lambda: om.lm_forward(sd, c, emb, cache))
+            tok = torch.tensor([int(torch.argmax(logits[0]))])
+            t_d, _ = timed(lambda: [om.lm_forward(sd, c, sd["model.embed_tokens.weight"][tok], cache) for _ in range(n_dec)])
+            res[layers] = (t_p, t_d / n_dec)
+    VL, LL = cfg.vision.num_hidden_layers, cfg.num_hidden_layers
+    t_vit = t_v0 + (t_v1 - t_v0) * VL
+    t_prefill = res[0][0] + (res[1][0] - res[0][0]) * LL
+    t_step = res[0][1] + (res[1][1] - res[0][1]) * LL
+    t_page = t_vit + t_prefill + t_step * (max_new_tokens - 1)
+    measured = t_v0 + t_v1 + sum(r[0] + r[1] * n_dec for r in res.values())
+    return {"value": 1.0 / t_page, "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"fp32 oracle on ONE full synthetic A4 page ({pv.shape[0]} patches, {len(ids)} prompt tokens, {max_new_tokens} new tokens), "
+                      f"{measured:.1f} s measured: ViT with 0 and 1 of {VL} blocks, LM prefill and {n_dec} decode steps with 0 and 1 of {LL} layers; "
+                      f"extrapolated by layer count to {t_page:.0f} s per page (ViT {t_vit:.0f} s, prefill {t_prefill:.0f} s, "
+                      f"decode {t_step * 1e3:.0f} ms/token = {1.0 / t_step:.2f} tok/s)"}
+
+
+def mixed_pages(n_total, seed=2025):
+    import random
+    rng = random.Random(seed)
+    sizes, weights = zip(*MIXED_SIZES)
+    return [rng.choices(sizes, weights)[0] for _ in range(n_total)]
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(a)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,33 +143,54 @@ def main():
     from dots_ocr_amd import dp
     from dots_ocr_amd.config import DotsConfig
     from dots_ocr_amd.engine import Engine
-    from dots_ocr_amd.image_utils import preprocess_image
-    from dots_ocr_amd.synthetic import A4_200DPI, HIGH_RES, synth_page, synth_prompt_ids
+    from dots_ocr_amd.image_utils import smart_resize
+    from dots_ocr_amd.processing import IMG_PAD, DotsOcrProcessor
+    from dots_ocr_amd.synthetic import A4_200DPI, HIGH_RES, synth_page
     from dots_ocr_amd.weights import random_state_dict
 
-    if a.workload == "tiny":
-        cfg, size = DotsConfig.tiny(layers=4, v_layers=4), (420, 588)
-    else:
-        cfg, size = DotsConfig(), (A4_200DPI if a.workload == "a4" else HIGH_RES)
+    cfg = DotsConfig.tiny(layers=4, v_layers=4) if a.workload == "tiny" else DotsConfig()
+    mixed = a.workload == "mixed64"
     B = a.batch
     t_setup = time.perf_counter()
     sd = random_state_dict(cfg, seed=a.seed, threads=min(32, os.cpu_count() or 8))
+    v = cfg.vision
+    factor = v.patch_size * v.spatial_merge_size
 
-    # ---- this rank's shard of the page batch (weak scaling: B pages per GPU), preprocessed on the host
-    pages = [synth_page(rank * B + i, size) for i in range(B)]
-    feats, grids = zip(*(preprocess_image(p) for p in pages))
-    pv = np.concatenate(feats, 0)
-    grid = np.asarray(grids, np.int64)
-    n_vis = [int(g[1] * g[2] // 4) for g in grid]
-    prompts = [synth_prompt_ids(cfg, n, seed=rank * B + i) for i, n in enumerate(n_vis)]
-    ids = np.concatenate(prompts)
-    lens = np.asarray([len(p) for p in prompts], np.int32)
-    max_seq = int(lens.max()) + a.max_new_tokens + 64
+    def patches_of(size):
+        rh, rw = smart_resize(size[1], size[0], factor, cfg.min_pixels, cfg.max_pixels)
+        return (rh // v.patch_size) * (rw // v.patch_size)
 
-    eng = Engine(cfg, device=local, max_batch=B, max_seq_len=max_seq, max_patches=pv.shape[0] + 64,
-                 max_prefill_tokens=int(lens.sum()) + 64)
+    # ---- this rank's pages
+    if mixed:
+        sizes_all = mixed_pages(64)
+        shards = dp.shard_pages([dp.page_cost(patches_of(sz), a.max_new_tokens) for sz in sizes_all], world)
+        my_pages = shards[rank]
+        n_job_pages = len(sizes_all)
+    else:
+        size = (420, 588) if a.workload == "tiny" else (A4_200DPI if a.workload == "a4" else HIGH_RES)
+        sizes_all = None
+        my_pages = [rank * B + i for i in range(B)]
+        n_job_pages = world * B
+    sizes = [sizes_all[i] if mixed else size for i in my_pages]
+    pages = [synth_page(i, sz) for i, sz in zip(my_pages, sizes)]
+    n_patches = [patches_of(sz) for sz in sizes]
+    max_prompt = max(n_patches) // 4 + N_TEXT_TOKENS + 3
+    max_seq = max_prompt + a.max_new_tokens + 64
+    slots = B
+    max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
+    eng = Engine(cfg, device=local, max_batch=slots, max_seq_len=max_seq, max_patches=max_patches,
+                 max_prefill_tokens=slots * max_prompt + 64)
     eng.load_state_dict(sd)
-    pix_dev = eng.to_device(pv)                      # inputs resident in HBM before the timed region
+    proc = DotsOcrProcessor(cfg, engine=eng)
+    prompt_text = json.loads((ROOT / "dots_ocr_amd" / "data" / "prompts.json").read_text())["prompt_layout_all_en"]
+    messages = [{"role": "user", "content": [{"type": "image", "image": "page"}, {"type": "text", "text": prompt_text}]}]
+
+    # inputs resident in HBM before the timed region: the uint8 pixels of every page; one fp32 patch buffer is reused
+    page_arrays = [np.ascontiguousarray(np.asarray(p.convert("RGB"), dtype=np.uint8)) for p in pages]
+    page_dev = [eng.to_device(arr) for arr in page_arrays]
+    pix = torch.empty((sum(n_patches), v.patch_dim), dtype=torch.float32, device=torch.device("cuda", local))
+    pix_dev = pix.data_ptr()
+    torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
     def barrier():
@@ -118,73 +198,131 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    host_ms = {"tokenize_ms": 0.0, "preprocess_ms": 0.0, "detokenize_ms": 0.0}
+
+    def tokenize(n_vis, page_no):
+        """chat template -> ids.  The stand-in byte tokenizer (no checkpoint tokenizer exists offline) makes ~4x more
+        tokens than BPE for the text part, so the text is clipped to the BPE-equivalent length: the prompt keeps the
+        BASELINE shape (3 + n_vis + 241 + ... = 5 200 tokens for an A4 page) while its tokenisation is really executed."""
+        text = proc.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        head, tail = text.split(IMG_PAD)                           # "<|user|><|img|>" | "<|endofimg|>{prompt}<|endofuser|><|assistant|>"
+        h_ids, t_ids = proc.tokenizer.encode(head), proc.tokenizer.encode(tail)
+        rng = np.random.default_rng(page_no)                       # distinct prompts per page, like distinct documents
+        body = np.asarray(t_ids[1:-2][:N_TEXT_TOKENS - 2], np.int64)
+        body = (body + rng.integers(0, 200, len(body))) % 256      # still byte ids
+        return np.concatenate([h_ids, [cfg.image_token_id] * n_vis, t_ids[:1], body, t_ids[-2:]]).astype(np.int32)
+
     def step():
-        return eng.generate(ids, lens, pix_dev, grid, a.max_new_tokens, (), pixel_on_device=True)
+        t0 = time.perf_counter()
+        prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
+        t1 = time.perf_counter()
+        grids, off = [], 0
+        for dptr, arr, n in zip(page_dev, page_arrays, n_patches):
+            grids.append(eng.preprocess_image(dptr, pix_dev + off * v.patch_dim * 4, shape=arr.shape[:2]))
+            off += n
+        t2 = time.perf_counter()
+        grid = np.asarray(grids, np.int64)
+        if mixed:
+            from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+            reqs, off = [], 0
+            for pr, g, n in zip(prompts, grids, n_patches):
+                reqs.append(Request(pr, pix[off:off + n], np.asarray([g], np.int64), a.max_new_tokens))
+                off += n
+            outs = ContinuousBatcher(eng, eos_ids=()).run(reqs)
+            out = np.zeros((len(outs), a.max_new_tokens), np.int32)
+            out_lens = np.zeros(len(outs), np.int32)
+            for i, o in enumerate(outs):
+                out[i, :len(o)], out_lens[i] = o, len(o)
+        else:
+            ids = np.concatenate(prompts)
+            lens = np.asarray([len(p) for p in prompts], np.int32)
+            out, out_lens = eng.generate(ids, lens, pix_dev, grid, a.max_new_tokens, (), pixel_on_device=True)
+        t3 = time.perf_counter()
+        texts = proc.batch_decode([out[i, :out_lens[i]] for i in range(len(out_lens))])
+        t4 = time.perf_counter()
+        host_ms["tokenize_ms"] += (t1 - t0) * 1e3
+        host_ms["preprocess_ms"] += (t2 - t1) * 1e3
+        host_ms["detokenize_ms"] += (t4 - t3) * 1e3
+        return out, out_lens, texts, prompts
 
     for _ in range(a.warmup):
         step()
+    for k in host_ms:
+        host_ms[k] = 0.0
     eng.synchronize(); torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
     phase = {"vit_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "vit_attn_ms": 0.0}
     last = None
     for _ in range(a.steps):
-        out, out_lens = step()
-        st = eng.stats()                             # device-side HIP-event times of this step
+        out, out_lens, texts, prompts = step()
+        st = eng.stats()                             # device-side HIP-event times of this step (static batches only)
         for k in phase:
             phase[k] += st[k]
         last = st
     eng.synchronize(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     # the only data-path collective: gather the generated token ids on rank 0
-    gathered = dp.gather_token_ids(out, out_lens, page_index=[rank * B + i for i in range(B)])
+    gathered = dp.gather_token_ids(out, out_lens, page_index=my_pages)
+    n_ranks = 1
     if use_dist:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)                        # how many ranks RCCL really sees
+        n_ranks = int(ones.item())
 
     if rank == 0:
         K = a.steps
-        pages_total = world * B * K
-        new_tok = int(out_lens.sum()) * world * K
-        attn_s = phase["vit_attn_ms"] / 1e3
-        attn_tflops = last["vit_attn_flops"] * K / attn_s / 1e12 if attn_s > 0 else 0.0
-        dec_s = phase["decode_ms"] / 1e3
-        dec_gbs = last["decode_bytes"] * K / dec_s / 1e9 if dec_s > 0 else 0.0
-        vit_s = phase["vit_ms"] / 1e3
-        traffic = None
-        tf = ROOT / "profiles" / "r01_flash_attn_traffic.json"
-        if a.workload == "a4" and B == 8 and tf.exists():
-            # HBM-side bytes per launch of the roofline kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # over this same command (corrected as MI355X_MICROARCH.md §HBM prescribes); see the file for the method.
-            traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
+        pages_total = n_job_pages * K
+        new_tok = sum(len(t) for _, t in gathered) * K
         res = {
-            "metric": f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (ViT + prefill + {a.max_new_tokens}-token greedy decode)",
+            "metric": f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)",
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic pages (PIL text lines), seeded random weights at the checkpoint's dimensions",
-            "config": {"workload": f"{a.workload}: {B} pages/GPU of {size[0]}x{size[1]} px -> {int(pv.shape[0] // B)} patches, "
-                                   f"{int(lens[0])} prompt tokens/page, max_new_tokens={a.max_new_tokens}, EOS disabled",
-                       "pages_per_gpu": B, "parallelism": f"dp{world}"},
-            "output_tok_s": new_tok / dt,
-            "decode_tok_s": int(out_lens.sum()) * K / dec_s if dec_s > 0 else None,
-            "phase_ms_per_step": {k: v / K for k, v in phase.items()},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
-                         "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": attn_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_flash_attn_traffic.json)",
-                         "algorithmic_flops_per_launch": last["vit_attn_flops"] / max(1, last["vit_attn_launches"]),
-                         "launches_per_step": last["vit_attn_launches"],
-                         "avg_launch_ms": phase["vit_attn_ms"] / K / max(1, last["vit_attn_launches"])},
-            "roofline_vit": {"bound": "mfma", "achieved": last["vit_flops"] * K / vit_s / 1e12 if vit_s > 0 else 0.0,
-                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                             "frac": (last["vit_flops"] * K / vit_s / 1e12 / PEAK_BF16_TFLOPS) if vit_s > 0 else 0.0},
-            "roofline_decode": {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": dec_gbs / PEAK_HBM_GBS, "ms_per_decode_step": phase["decode_ms"] / K / max(1, last["decode_steps"])},
-            "gathered_pages": len(gathered), "setup_s": setup_s,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if mixed else "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic pages (PIL text lines) as uint8 pixels in HBM, seeded random weights at the checkpoint's dimensions",
+            "output_tok_s": new_tok / dt, "rccl_ranks": n_ranks, "gathered_pages": len(gathered), "setup_s": setup_s,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if mixed:
+            from collections import Counter
+            res["config"] = {"workload": "mixed64: 64 pages " + ", ".join(f"{n}x {w}x{h}" for (w, h), n in sorted(Counter(sizes_all).items())) +
+                                         f"; cost-sharded (LPT) over {world} rank(s), continuous batching over {slots} slots per rank, "
+                                         f"max_new_tokens={a.max_new_tokens}, EOS disabled",
+                             "pages_per_gpu": [len(s) for s in shards], "parallelism": f"dp{world}"}
+        else:
+            res["config"] = {"workload": f"{a.workload}: {B} pages/GPU of {size[0]}x{size[1]} px -> {n_patches[0]} patches, "
+                                         f"{len(prompts[0])} prompt tokens/page, max_new_tokens={a.max_new_tokens}, EOS disabled",
+                             "pages_per_gpu": B, "parallelism": f"dp{world}"}
+            attn_s, dec_s, vit_s = phase["vit_attn_ms"] / 1e3, phase["decode_ms"] / 1e3, phase["vit_ms"] / 1e3
+            attn_tflops = last["vit_attn_flops"] * K / attn_s / 1e12 if attn_s > 0 else 0.0
+            dec_gbs = last["decode_bytes"] * K / dec_s / 1e9 if dec_s > 0 else 0.0
+
+            def recorded(name, key):            # PMC numbers come from separate rocprofv3 --pmc passes over this same command
+                f = ROOT / "profiles" / name
+                if a.workload == "a4" and B == 8 and f.exists():
+                    return json.loads(f.read_text()).get(key)
+                return None
+            res["decode_tok_s"] = int(out_lens.sum()) * K / dec_s if dec_s > 0 else None
+            res["phase_ms_per_step"] = {**{k: val / K for k, val in phase.items()}, **{k: val / K for k, val in host_ms.items()}}
+            res["roofline"] = {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
+                               "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tflops / PEAK_BF16_TFLOPS,
+                               "traffic": recorded("r01_flash_attn_traffic.json", "traffic_bytes_per_launch"),
+                               "traffic_unit": "bytes/launch (PMC, profiles/r01_flash_attn_traffic.json)",
+                               "algorithmic_flops_per_launch": last["vit_attn_flops"] / max(1, last["vit_attn_launches"]),
+                               "launches_per_step": last["vit_attn_launches"],
+                               "avg_launch_ms": phase["vit_attn_ms"] / K / max(1, last["vit_attn_launches"])}
+            res["roofline_vit"] = {"bound": "mfma", "achieved": last["vit_flops"] * K / vit_s / 1e12 if vit_s > 0 else 0.0,
+                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": (last["vit_flops"] * K / vit_s / 1e12 / PEAK_BF16_TFLOPS) if vit_s > 0 else 0.0}
+            res["roofline_decode"] = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS,
+                                      "ms_per_decode_step": phase["decode_ms"] / K / max(1, last["decode_steps"]),
+                                      "algorithmic_bytes_per_decode_step": last["decode_bytes"] / max(1, last["decode_steps"]),
+                                      "traffic": recorded("r02_decode_traffic.json", "traffic_bytes_per_decode_step"),
+                                      "traffic_unit": "bytes per decode step (PMC, profiles/r02_decode_traffic.json)"}
+        if world == 1 and not a.no_cpu_baseline and a.workload == "a4":
             cores = min(os.cpu_count() or 1, 64)
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, cores)
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, cores, pages[0], prompts[0], a.max_new_tokens)
         print(json.dumps(res), flush=True)
     eng.close()
     if use_dist:

@@ -232,12 +232,20 @@ class Engine:
                                            C.c_void_p(out_dev) if out_dev else None), "dots_vit_forward")
         return n // (self.cfg.vision.spatial_merge_size ** 2)
 
-    def preprocess_image(self, rgb: np.ndarray, out_dev: int, min_pixels: Optional[int] = None, max_pixels: Optional[int] = None):
-        """uint8 [h, w, 3] host image -> float32 patches written at device pointer `out_dev`; returns [t, gh, gw].
+    def preprocess_image(self, rgb, out_dev: int, min_pixels: Optional[int] = None, max_pixels: Optional[int] = None,
+                         shape: Optional[Sequence[int]] = None):
+        """uint8 [h, w, 3] image -> float32 patches written at device pointer `out_dev`; returns [t, gh, gw].
+        `rgb` is a host numpy array, or (with shape=(h, w)) a device pointer to the uint8 pixels already in HBM.
         Bit-identical to image_utils.preprocess_image (Pillow BICUBIC + normalise + patchify), computed on the GPU."""
         from .image_utils import bicubic_resample_tables, smart_resize
-        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-        h, w, _ = rgb.shape
+        on_device = shape is not None
+        if on_device:
+            h, w = int(shape[0]), int(shape[1])
+            rgb_ptr = C.c_void_p(int(rgb))
+        else:
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            h, w, _ = rgb.shape
+            rgb_ptr = rgb.ctypes.data_as(C.c_void_p)
         v = self.cfg.vision
         rh, rw = smart_resize(h, w, v.patch_size * v.spatial_merge_size, min_pixels or self.cfg.min_pixels, max_pixels or self.cfg.max_pixels)
         hc = hb = vc = vb = None
@@ -252,7 +260,7 @@ class Engine:
         std = np.asarray(self.cfg.image_std, np.float32)
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         self._ck(self.lib.dots_preprocess_image(
-            self.h, rgb.ctypes.data_as(C.c_void_p), 0, h, w, rh, rw,
+            self.h, rgb_ptr, int(on_device), h, w, rh, rw,
             _i32p(hc) if hc is not None else None, _i32p(hb) if hb is not None else None, hk,
             _i32p(vc) if vc is not None else None, _i32p(vb) if vb is not None else None, vk,
             fp(mean), fp(std), float(np.float32(1.0 / 255.0)), C.c_void_p(out_dev)), "dots_preprocess_image")

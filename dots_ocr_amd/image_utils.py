@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import base64
 import copy
+import functools
 import math
 from io import BytesIO
 from typing import Sequence, Tuple
@@ -144,6 +145,7 @@ def preprocess_image(image: Image.Image, patch_size: int = 14, merge_size: int =
 
 
 # ------------------------------------------------------------------------------ device preprocessing (host half)
+@functools.lru_cache(maxsize=64)
 def bicubic_resample_tables(in_size: int, out_size: int):
     """Fixed-point tap tables of Pillow's BICUBIC resampler for one axis (vectorised): int32 coeffs [out, ksize] and
     int32 bounds [out, 2] = (first input index, tap count).  The GPU kernels (csrc/preprocess.hip) apply them with

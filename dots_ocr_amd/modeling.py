@@ -142,7 +142,7 @@ class DotsOcrHipForCausalLM:
         if pixel_values is not None:
             if pixel_values.is_cuda:
                 pv_dev = pixel_values.contiguous().float()
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.synchronize(pv_dev.device)
             else:
                 pv_host = np.ascontiguousarray(pixel_values.detach().numpy(), dtype=np.float32)
 

@@ -104,7 +104,7 @@ class ContinuousBatcher:
                 import torch
                 pv = pvs[0] if len(pvs) == 1 else torch.cat(pvs, dim=0)
                 pv = pv.contiguous().float()
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.synchronize(pv.device)
                 self.engine.vit_forward(pv.data_ptr(), grid, on_device=True)
                 self.engine.synchronize()            # `pv` may be a temporary
             else:
