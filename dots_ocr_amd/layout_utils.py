@@ -1,8 +1,7 @@
 """Host-side handling of the model's layout JSON (reference dots_ocr/utils/layout_utils.py:115-228).
-This consumes the hot path's OUTPUT string and is outside the accelerated path; only
-what DotsOCRParser needs is provided: bbox rescaling both ways and JSON decoding with a failure flag.
-The reference's regex repair of malformed generations (OutputCleaner, #12) is not rebuilt: a response
-that does not parse is returned verbatim with filtered=True, as the reference does after cleaning."""
+This consumes the hot path's OUTPUT string and is outside the accelerated path; what
+DotsOCRParser needs is provided: bbox rescaling both ways, JSON decoding with a failure flag, and the
+reference's salvage of malformed generations (output_cleaner.OutputCleaner, layout_utils.py:221-228)."""
 from __future__ import annotations
 
 import json
@@ -43,13 +42,21 @@ def post_process_output(response, prompt_mode, origin_image, input_image, min_pi
     """-> (cells, filtered).  Plain-text modes return the response unchanged."""
     if prompt_mode in ("prompt_ocr", "prompt_table_html", "prompt_table_latex", "prompt_formula_latex"):
         return response
+    cells = response
     try:
-        cells = post_process_cells(origin_image, json.loads(response), input_image.width, input_image.height,
-                                   min_pixels=min_pixels, max_pixels=max_pixels)
-        return cells, False
-    except Exception as e:                       # malformed generation
+        cells = json.loads(cells)
+        return post_process_cells(origin_image, cells, input_image.width, input_image.height, min_pixels=min_pixels, max_pixels=max_pixels), False
+    except Exception as e:                       # malformed generation (typically cut off at max_new_tokens)
         print(f"cells post process error: {e}, when using {prompt_mode}")
-        return response, True
+    from .output_cleaner import OutputCleaner
+    salvaged = OutputCleaner().clean_model_output(cells)      # `cells`: the parsed object if only the rescaling failed
+    if isinstance(salvaged, list):
+        salvaged = "\n\n".join(c["text"] for c in salvaged if "text" in c)
+    return salvaged, True
+
+
+def is_legal_bbox(cells) -> bool:
+    return all(c["bbox"][2] > c["bbox"][0] and c["bbox"][3] > c["bbox"][1] for c in cells)
 
 
 def draw_layout_on_image(image, cells):

@@ -183,31 +183,64 @@ class ContinuousWorker(BatchingWorker):
                 cb, key = None, None
 
 
-def _parse_messages(messages):
-    """OpenAI chat messages -> (PIL image or None, chat-template text).  The reference client writes the image
-    placeholder tokens into its text part itself (model/inference.py:33); if they are missing they are added."""
-    image, parts, system = None, [], ""
+def _load_request_image(url: str, allow_remote: bool, allow_local: bool):
+    """Image of a chat request.  Default: `data:image/...;base64,` URLs only — all the reference client sends
+    (model/inference.py:20-33).  http(s) URLs and local paths are opt-in server flags: the server listens on 0.0.0.0, so
+    resolving client-supplied locations would let a remote caller read local files or reach internal services (SSRF)."""
+    if not isinstance(url, str):
+        raise ValueError("image_url must be a string")
+    if url.startswith("data:image"):
+        return fetch_image(url)
+    if url.startswith(("http://", "https://")):
+        if not allow_remote:
+            raise ValueError("remote image URLs are disabled (start the server with --allow-remote-images)")
+        import requests
+        from io import BytesIO
+        from PIL import Image
+        resp = requests.get(url, timeout=(3.0, 10.0), stream=True)
+        resp.raise_for_status()
+        data = resp.raw.read(64 * 1024 * 1024 + 1, decode_content=True)
+        if len(data) > 64 * 1024 * 1024:
+            raise ValueError("remote image larger than 64 MiB")
+        return fetch_image(Image.open(BytesIO(data)))
+    if not allow_local:
+        raise ValueError("local image paths are disabled (start the server with --allow-local-images)")
+    return fetch_image(url)
+
+
+def _parse_messages(messages, processor=None, allow_remote: bool = False, allow_local: bool = False):
+    """OpenAI chat messages -> (PIL image or None, chat-template text).  The text is rendered by the processor's chat
+    template (the checkpoint's own Jinja template when it ships one).  The reference client writes the image placeholder
+    tokens into its text part itself (model/inference.py:33); a client that sends them and an image part gets ONE image."""
+    image, conv = None, []
     for m in messages:
-        content = m.get("content")
-        if m.get("role") == "system":
-            system += content if isinstance(content, str) else "".join(c.get("text", "") for c in content)
-            continue
+        role, content = m.get("role", "user"), m.get("content")
         if isinstance(content, str):
-            parts.append(content)
+            conv.append({"role": role, "content": [{"type": "text", "text": content}]})
             continue
+        items = []
         for c in content or []:
             if c.get("type") == "image_url":
                 url = c["image_url"]["url"] if isinstance(c["image_url"], dict) else c["image_url"]
-                image = fetch_image(url)
+                image = _load_request_image(url, allow_remote, allow_local)
+                items.append({"type": "image", "image": "request"})
             elif c.get("type") == "text":
-                parts.append(c["text"])
-    body = "".join(parts)
-    if image is not None and IMG_PAD not in body:
-        body = IMG_START + IMG_PAD + IMG_END + body
-    return image, system + USER + body + END_USER + ASSISTANT
+                items.append({"type": "text", "text": c["text"]})
+        conv.append({"role": role, "content": items})
+    if any(IMG_PAD in it.get("text", "") for m in conv for it in m["content"]):       # placeholders already in the text
+        for m in conv:
+            m["content"] = [it for it in m["content"] if it.get("type") != "image"]
+    if processor is not None:
+        return image, processor.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)
+    out = []                                          # no processor (unit tests): the stand-in template
+    for m in conv:
+        body = "".join(IMG_START + IMG_PAD + IMG_END if it.get("type") == "image" else it.get("text", "") for it in m["content"])
+        out.append(body if m["role"] == "system" else (USER + body + END_USER if m["role"] == "user" else ASSISTANT + body))
+    return image, "".join(out) + ASSISTANT
 
 
-def create_app(model, processor, model_name: str = "model", max_batch: int = 8, max_wait_ms: float = 5.0, continuous: Optional[bool] = None):
+def create_app(model, processor, model_name: str = "model", max_batch: int = 8, max_wait_ms: float = 5.0, continuous: Optional[bool] = None,
+               allow_remote_images: bool = False, allow_local_images: bool = False):
     from fastapi import FastAPI, HTTPException
     from fastapi.concurrency import run_in_threadpool
 
@@ -232,8 +265,8 @@ def create_app(model, processor, model_name: str = "model", max_batch: int = 8, 
         messages = req.get("messages")
         if not messages:
             raise HTTPException(400, "messages is required")
-        try:
-            image, text = _parse_messages(messages)
+        try:            # decoding (and, when enabled, fetching) an image must not stall the event loop
+            image, text = await run_in_threadpool(_parse_messages, messages, processor, allow_remote_images, allow_local_images)
         except Exception as e:
             raise HTTPException(400, f"bad message content: {e}")
         max_tokens = int(req.get("max_completion_tokens") or req.get("max_tokens") or 16384)
@@ -269,6 +302,8 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--max-batch", type=int, default=8)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--static-batching", action="store_true", help="static batches through model.generate instead of continuous batching")
+    ap.add_argument("--allow-remote-images", action="store_true", help="let requests name http(s) image URLs (off: data: URLs only)")
+    ap.add_argument("--allow-local-images", action="store_true", help="let requests name image paths on the server's file system")
     a = ap.parse_args(argv)
     import uvicorn
     from .modeling import DotsOcrHipForCausalLM
@@ -279,7 +314,8 @@ def main(argv: Optional[List[str]] = None):
     else:
         model = DotsOcrHipForCausalLM.from_pretrained(a.model_path, device=a.device, max_batch=a.max_batch)
         proc = DotsOcrProcessor.from_pretrained(a.model_path, engine=model.engine)
-    uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch, continuous=not a.static_batching), host=a.host, port=a.port)
+    uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch, continuous=not a.static_batching,
+                           allow_remote_images=a.allow_remote_images, allow_local_images=a.allow_local_images), host=a.host, port=a.port)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,10 @@ JSON fixtures:
                      every fixture image size in the reference tree and a seeded random sweep.
   ../../dots_ocr_amd/data/prompts.json   the 8 task prompts (reference dots_ocr/utils/prompts.py:1-46),
                      which are model inputs and must be byte-identical.
+  format_transformer.json  input -> output of get_formula_in_markdown / clean_text / layoutjson2md / fix_streamlit_formulas
+                     (reference dots_ocr/utils/format_transformer.py) on hand-written and mutated cases.
+  output_cleaner.json      input -> OutputCleaner().clean_model_output(input) (reference dots_ocr/utils/output_cleaner.py)
+                     on valid, truncated, glued, repeated and degenerate layout JSON, plus a seeded mutation sweep.
 """
 import importlib.util
 import json
@@ -71,6 +75,70 @@ def main():
     (data / "prompts.json").write_text(json.dumps(pr.dict_promptmode_to_prompt, ensure_ascii=False, indent=1))
     (HERE / "prompts.json").write_text(json.dumps(pr.dict_promptmode_to_prompt, ensure_ascii=False, indent=1))
     print(f"wrote {len(out)} smart_resize cases, {len(pr.dict_promptmode_to_prompt)} prompts")
+    post_processing_goldens(rng)
+
+
+def post_processing_goldens(rng):
+    import contextlib
+    import io
+    ft = _load("dots_ocr.utils.format_transformer", REF / "dots_ocr/utils/format_transformer.py")
+    oc = _load("dots_ocr.utils.output_cleaner", REF / "dots_ocr/utils/output_cleaner.py")
+    formulas = ["$x^2$", "E = mc", "$$a$$ and $$b$$", "$$ a + b $$", "$$a$b$$", "$$", "$$$", "\\[ x \\]", "see \\[ x \\] here", "\\frac{a}{b}",
+                "  \\alpha + \\beta  ", "`\\sum_i x_i`", "\\documentclass{article}\\usepackage{amsmath}\\begin{document}\\frac12\\end{document}",
+                "\\usepackage[utf8]{inputenc} \\sqrt{2}", "\\( y \\)", "\\begin{align} a &= b \\end{align}", "plain text", "", "   ", "$", "a $ b", "x\n\\[ y \\]\nz",
+                "\\[ a \\] trailing", "$$\na\n$$", "`$x$`", "\\mathbb{R}", "100% \\$5", "\\[\n a \n\\]", "$$ $$"]
+    texts = ["`$x$`", " padded ", "", None, "`$a$` and more", "`$`", "`$$`", "plain", "`$x$", "\t`$y$`\n"]
+    md_cases = ["$$a$$", "$$\na\n$$", "x $$a$$ y $$\nb$$ z", "no formula", "$$\n\na\n\n$$", "$$a\n$$ $$\nb$$"]
+    cells_cases = [
+        [{"bbox": [0, 0, 10, 10], "category": "Text", "text": " hello "}, {"bbox": [1.0, 2.0, 3.9, 4.2], "category": "Formula", "text": "\\frac{a}{b}"},
+         {"bbox": [0, 0, 5, 5], "category": "Page-header", "text": "head"}, {"bbox": [0, 0, 5, 5], "category": "Page-footer", "text": "foot"},
+         {"bbox": [0, 0, 5, 5], "category": "Table", "text": "<table></table>"}, {"bbox": [0, 0, 5, 5], "category": "Title"}],
+        [], [{"bbox": ["3", "4", "5", "6"], "category": "Formula", "text": "$x$"}]]
+    out = {"get_formula_in_markdown": [[t, ft.get_formula_in_markdown(t)] for t in formulas],
+           "clean_text": [[t, ft.clean_text(t)] for t in texts],
+           "fix_streamlit_formulas": [[t, ft.fix_streamlit_formulas(t)] for t in md_cases],
+           "layoutjson2md": [[c, hf, ft.layoutjson2md(None, c, "text", hf)] for c in cells_cases for hf in (False, True)]}
+    (HERE / "format_transformer.json").write_text(json.dumps(out, ensure_ascii=False, indent=1))
+
+    def cell(i, text=None, cat="Text"):
+        d = {"bbox": [10 * i, 20 * i, 10 * i + 50, 20 * i + 30], "category": cat}
+        if text is not None:
+            d["text"] = text
+        return d
+    valid = json.dumps([cell(1, "alpha"), cell(2, "beta {braces}"), cell(3, None, "Picture"), cell(4, 'delta "quoted"')], ensure_ascii=False)
+    cases = [valid, valid[:-1], valid[:-20], valid[:60], valid.replace("}, {", "}{"), valid.replace("}, {", "} {"), valid[1:], valid + ",",
+             "[" + ", ".join([json.dumps(cell(1, "rep"))] * 4) + "]", "[" + ", ".join([json.dumps(cell(1, "rep"))] * 4) + ", " + json.dumps(cell(2, "x"))[:25],
+             json.dumps([cell(i, "same") for i in range(7)]), json.dumps([cell(i % 2, f"t{i}") for i in range(6)]),
+             '[{"bbox": [1, 2, 3, 4], "category": "Text", "text": "unterminated', '[{"bbox": [1, 2, 3], "category": "Text", "text": "unterminated',
+             '[{"bbox": [1, 2, 3, 4], "text": "no category', '[{"bbox": [1, 2, x, 4], "category": "Text"', "", "not json at all", "[]", "{}", "42", "null",
+             '{"bbox": [1,2,3,4], "category": "Text", "text": "bare object"}', '[{"category": "Text", "text": "no bbox"}]',
+             json.dumps([cell(1, "a")]) * 2, valid[:-1] * 30, "[" + ", ".join(json.dumps(cell(i, "long " * 40)) for i in range(400)) + "]",
+             [cell(1, "list"), {"bbox": [1, 2, 3], "category": "Text", "text": "three"}, {"bbox": [1, 2, 3]}, {"bbox": "bad", "category": "x"}, "str", {"category": "Title"}, {"text": "orphan"}],
+             [cell(1, "dup"), cell(1, "dup2"), cell(2, "p"), cell(3, "p"), cell(4, "p"), cell(5, "p"), cell(6, "p")], [], [cell(1, "only")]]
+    for _ in range(120):                                                         # seeded mutation sweep over a valid page
+        n = rng.randint(1, 9)
+        s = json.dumps([cell(rng.randint(1, 5), rng.choice(["a", "b}", "{c", "d\n", None]), rng.choice(["Text", "Table", "Formula"])) for _ in range(n)])
+        for _ in range(rng.randint(1, 3)):
+            op = rng.randint(0, 4)
+            if op == 0:
+                s = s[:rng.randint(0, len(s))]
+            elif op == 1:
+                s = s.replace("}, {", rng.choice(["}{", "} {", "}\n{"]), rng.randint(1, 3))
+            elif op == 2 and len(s) > 4:
+                a = rng.randint(0, len(s) - 2)
+                s = s[:a] + s[a + rng.randint(1, 3):]
+            elif op == 3:
+                s = s + s[rng.randint(0, len(s)):]
+            else:
+                s = s.replace('"bbox"', '"bbox" ', 1)
+        cases.append(s)
+    res = []
+    for c in cases:
+        with contextlib.redirect_stdout(io.StringIO()):
+            got = oc.OutputCleaner().clean_model_output(c)
+        res.append([c, got])
+    (HERE / "output_cleaner.json").write_text(json.dumps(res, ensure_ascii=False))
+    print(f"wrote {sum(len(v) for v in out.values())} format_transformer cases, {len(res)} output_cleaner cases")
 
 
 if __name__ == "__main__":

@@ -150,3 +150,27 @@ def test_continuous_worker_keeps_slots_full_and_separates_sampling_parameters():
         # a capped request reports "length"
         d = c.post("/v1/chat/completions", json=_payload(synth_page(0, sizes[0]), max_completion_tokens=3)).json()
         assert d["choices"][0]["finish_reason"] == "length" and d["usage"]["completion_tokens"] == 3
+
+
+def test_server_refuses_remote_and_local_image_locations_by_default(tmp_path):
+    """a client-supplied image_url must not make the server read local files or fetch URLs (SSRF) unless the
+    operator opted in; data: URLs (all the reference client sends, model/inference.py:20-33) always work."""
+    from PIL import Image
+    from dots_ocr_amd.image_utils import PILimage_to_base64
+    from dots_ocr_amd.server import _parse_messages
+    p = tmp_path / "secret.png"
+    Image.new("RGB", (32, 32), "red").save(p)
+
+    def msg(url):
+        return [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": url}}, {"type": "text", "text": "read"}]}]
+    for url in (str(p), "file://" + str(p), "http://169.254.169.254/latest/meta-data", "https://example.invalid/x.png"):
+        with pytest.raises(ValueError):
+            _parse_messages(msg(url))
+    img, text = _parse_messages(msg(PILimage_to_base64(Image.new("RGB", (28, 28), "blue"))))
+    assert img.size == (28, 28) and text.count("<|imgpad|>") == 1 and text.endswith("<|assistant|>")
+    img, _ = _parse_messages(msg(str(p)), allow_local=True)
+    assert img.size == (32, 32)
+    # the reference client puts the placeholder tokens into its text itself: still exactly one image slot
+    own = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": PILimage_to_base64(Image.new("RGB", (28, 28)))}},
+                                         {"type": "text", "text": "<|img|><|imgpad|><|endofimg|>read"}]}]
+    assert _parse_messages(own)[1].count("<|imgpad|>") == 1
