@@ -6,7 +6,7 @@ from dots_ocr_amd.image_utils import PILimage_to_base64
 
 
 def inference_with_vllm(image, prompt, protocol="http", ip="localhost", port=8000, temperature=0.1, top_p=0.9,
-                        max_completion_tokens=32768, model_name="rednote-hilab/dots.ocr", system_prompt=None):
+                        max_completion_tokens=32768, model_name="rednote-hilab/dots.mocr", system_prompt=None):
     import requests
     from openai import OpenAI        # optional dependency, imported lazily
     client = OpenAI(api_key=os.environ.get("API_KEY", "0"), base_url=f"{protocol}://{ip}:{port}/v1")

@@ -108,6 +108,12 @@ def fetch_image(image, min_pixels=None, max_pixels=None, resized_height=None, re
     return img.resize((rw, rh))
 
 
+def get_input_dimensions(image, min_pixels: int, max_pixels: int, factor: int = 28):
+    """(width, height) the model sees for `image` (reference image_utils.py:142-167; used by the demo UIs)."""
+    h, w = smart_resize(image.height, image.width, factor=factor, min_pixels=min_pixels, max_pixels=max_pixels)
+    return w, h
+
+
 def get_image_by_fitz_doc(image, target_dpi: int = 200):
     """Re-render an image at `target_dpi` through a PDF round trip (needs PyMuPDF; reference :170-196)."""
     import fitz  # noqa: F401  (optional dependency, outside the accelerated path)

@@ -243,3 +243,43 @@ class DotsOCRParser:
             for r in results:
                 w.write(json.dumps(r, ensure_ascii=False) + "\n")
         return results
+
+
+def main(argv=None):
+    """The reference's command line (dots_ocr/parser.py:326-430), same arguments and defaults: `python dots_ocr/parser.py
+    <pdf or image> [--use_hf true] ...`.  --use_hf selects the in-process MI355X engine, otherwise the OpenAI-compatible
+    server at --protocol://--ip:--port (dots_ocr_amd.server, or any vLLM deployment)."""
+    import argparse
+    from .prompts import dict_promptmode_to_prompt
+    ap = argparse.ArgumentParser(description="dots.ocr Multilingual Document Layout Parser")
+    ap.add_argument("input_path", type=str, help="Input PDF/image file path")
+    ap.add_argument("--output", type=str, default="./output", help="Output directory (default: ./output)")
+    ap.add_argument("--prompt", choices=list(dict_promptmode_to_prompt.keys()), type=str, default="prompt_layout_all_en",
+                    help="prompt to query the model, different prompts for different tasks")
+    ap.add_argument("--bbox", type=int, nargs=4, metavar=("x1", "y1", "x2", "y2"), help="needed for prompt_grounding_ocr")
+    ap.add_argument("--protocol", type=str, choices=["http", "https"], default="http")
+    ap.add_argument("--ip", type=str, default="localhost")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--model_name", type=str, default="model")
+    ap.add_argument("--temperature", type=float, default=0.1)
+    ap.add_argument("--top_p", type=float, default=1.0)
+    ap.add_argument("--dpi", type=int, default=200)
+    ap.add_argument("--max_completion_tokens", type=int, default=16384)
+    ap.add_argument("--num_thread", type=int, default=16)
+    ap.add_argument("--no_fitz_preprocess", action="store_true",
+                    help="skip the PDF round trip that re-renders low-dpi images at --dpi (needs PyMuPDF)")
+    ap.add_argument("--min_pixels", type=int, default=None)
+    ap.add_argument("--max_pixels", type=int, default=None)
+    ap.add_argument("--use_hf", type=bool, default=False)
+    a = ap.parse_args(argv)
+    parser = DotsOCRParser(protocol=a.protocol, ip=a.ip, port=a.port, model_name=a.model_name, temperature=a.temperature, top_p=a.top_p,
+                           max_completion_tokens=a.max_completion_tokens, num_thread=a.num_thread, dpi=a.dpi, output_dir=a.output,
+                           min_pixels=a.min_pixels, max_pixels=a.max_pixels, use_hf=a.use_hf)
+    fitz_preprocess = not a.no_fitz_preprocess
+    if fitz_preprocess:
+        print("Using fitz preprocess for image input, check the change of the image pixels")
+    return parser.parse_file(a.input_path, prompt_mode=a.prompt, bbox=a.bbox, fitz_preprocess=fitz_preprocess)
+
+
+if __name__ == "__main__":
+    main()
