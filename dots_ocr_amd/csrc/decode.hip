@@ -15,6 +15,9 @@
 // Dense layers at M = B <= 16 rows (decode_fused.hip): skinny GEMM on MFMA with the weight tile as the A operand,
 // weights streamed straight to VGPRs (guide: "GEMV / M<=16: neither LDS nor glds"), split-K only across the waves of
 // one workgroup, reduced through LDS in a fixed order.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
@@ -111,16 +114,17 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const bf16_t* __restrict
 // result — depends on the sequence's own context only, not on what else is in the batch or on the schedule.
 // Splits past the context's last page exit at once and are not read by the combine kernel.
 // Memory round trips: {context length, first page id, q} in one, then the page itself (32 KiB per wave in flight).
-__global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
                                                           const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
                                                           int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
                                                           int Hq, int Hkv, int n_splits, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) float lds_o[4][16 * 128];
-    __shared__ float lds_m[4][16], lds_l[4][16];
+    __shared__ __attribute__((aligned(16))) float lds_o[NW][16 * 128];
+    __shared__ float lds_m[NW][16], lds_l[NW][16];
     const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
     const int group = Hq / Hkv;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
-    const int p0 = split * 4 + w;
+    const int p0 = split * NW + w;
     TRACE(0);
     const int ctx = ctx_len[b] + 1;                       // includes the token appended this step
     int page = block_table[b * max_pages + min(p0, max_pages - 1)];
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     for (int kk = 0; kk < 4; ++kk)
         qraw[kk] = *reinterpret_cast<const u32x4*>(q + ((size_t)b * Hq + hkv * group + min(i, group - 1)) * 128 + kk * 32 + g * 8);
     const int n_pages = (ctx + PAGE - 1) / PAGE;
-    if (split * 4 >= n_pages) return;
+    if (split * NW >= n_pages) return;
     TRACE(1);
     bf16x8 qf[4];
 #pragma unroll
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
     for (int dg = 0; dg < 8; ++dg) o[dg] = f32x4{0, 0, 0, 0};
     float m_run = -1e30f, l_run = 0.f;
 
-    for (int p = p0; p < n_pages; p += 4 * n_splits) {
+    for (int p = p0; p < n_pages; p += NW * n_splits) {
         if (p != p0) page = block_table[b * max_pages + p];
         const bf16_t* kp = pool + ((size_t)(page * Hkv + hkv) * 2) * PAGE_ELEMS;
         const bf16_t* vp = kp + PAGE_ELEMS;
@@ -216,13 +220,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const bf16_t* __restri
         for (int r = 0; r < 4; ++r) lds_o[w][i * 128 + dg * 16 + 4 * g + r] = o[dg][r];     // O^T[d = 16dg+4g+r][q = i]
     __syncthreads();
     TRACE(3);
-    // combine the 4 waves: thread -> (q head j, d) pairs
-    for (int item = threadIdx.x; item < group * 128; item += 256) {
+    // combine the NW waves: thread -> (q head j, d) pairs
+    for (int item = threadIdx.x; item < group * 128; item += NW * 64) {
         const int j = item >> 7, d = item & 127;
-        float m = fmaxf(fmaxf(lds_m[0][j], lds_m[1][j]), fmaxf(lds_m[2][j], lds_m[3][j]));
+        float m = lds_m[0][j];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) m = fmaxf(m, lds_m[ww][j]);
         float acc = 0.f, lsum = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
+        for (int ww = 0; ww < NW; ++ww) {
             const float f = __builtin_amdgcn_exp2f(lds_m[ww][j] - m);
             acc += lds_o[ww][j * 128 + d] * f;
             lsum += lds_l[ww][j] * f;
@@ -242,7 +248,7 @@ constexpr int CMB_BATCH = 32;
 
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                   const int32_t* __restrict__ ctx_len, bf16_t* __restrict__ out, int Hq,
-                                                                  int Hkv, int n_splits, int XR) {
+                                                                  int Hkv, int n_splits, int XR, int NW) {
     __shared__ float wts[64];
     __shared__ float inv_l;
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
     float pv[CMB_BATCH];
 #pragma unroll
     for (int s = 0; s < CMB_BATCH; ++s) pv[s] = po[(size_t)min(s, n_splits - 1) * stride];
-    const int n_used = min(n_splits, ((ctx + 1 + PAGE - 1) / PAGE + 3) / 4);       // splits that own at least one page
+    const int n_used = min(n_splits, ((ctx + 1 + PAGE - 1) / PAGE + NW - 1) / NW);       // splits that own at least one page
     if (d < 64) {
         const float m = d < n_used ? ml.x : -1e30f, l = d < n_used ? ml.y : 0.f;
         const float mg = wave_max(m);
@@ -464,18 +470,39 @@ hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows
     return hipGetLastError();
 }
 
+// Waves (= pages in flight) per decode-attention workgroup and with it the KV split: an ENGINE constant, never a function of the
+// batch (a sequence's partial sums must depend on its own context only).  DOTS_OCR_ATTN_WAVES overrides it for experiments.
+int decode_attn_waves() {
+    static const int nw = [] {
+        const char* e = getenv("DOTS_OCR_ATTN_WAVES");
+        const int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2) ? v : 4;
+    }();
+    return nw;
+}
+int decode_attn_splits(int max_seq_len) {
+    const int pages = (max_seq_len + PAGE - 1) / PAGE, nw = decode_attn_waves();
+    return std::max(1, std::min((pages + nw - 1) / nw, 64));
+}
+
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
                               int B, int Hq, int Hkv, int n_splits, float scale) {
     if (Hq % Hkv != 0 || Hq / Hkv > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(decode_attn_kernel, dim3(n_splits, Hkv, B), dim3(256), 0, s, q, pool_layer, ctx_len, block_table,
-                       max_pages, part_o, part_ml, Hq, Hkv, n_splits, scale * 1.44269504088896340736f);
+    const float sl = scale * 1.44269504088896340736f;
+    const dim3 grid(n_splits, Hkv, B);
+    switch (decode_attn_waves()) {
+        case 1: hipLaunchKernelGGL(decode_attn_kernel<1>, grid, dim3(64), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
+        case 2: hipLaunchKernelGGL(decode_attn_kernel<2>, grid, dim3(128), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
+        default: hipLaunchKernelGGL(decode_attn_kernel<4>, grid, dim3(256), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, const int32_t* ctx_len, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits) {
-    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, ctx_len, out, Hq, Hkv, n_splits, B <= 8 ? 8 : 16);
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, B), dim3(128), 0, s, part_o, part_ml, ctx_len, out, Hq, Hkv, n_splits, B <= 8 ? 8 : 16,
+                       decode_attn_waves());
     return hipGetLastError();
 }
 

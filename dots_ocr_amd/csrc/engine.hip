@@ -163,6 +163,11 @@ struct DotsEngine {
     int32_t* pp_tab = nullptr;
     size_t pp_in_cap = 0, pp_tmp_cap = 0, pp_out_cap = 0, pp_tab_cap = 0;
 
+    // ---- debug: residual stream after every ViT block / LM prefill layer (dots_debug_capture_hidden)
+    bf16_t* dbg_hidden = nullptr;
+    size_t dbg_cap = 0;                    // elements
+    int64_t dbg_vit_rows = 0, dbg_lm_rows = 0;
+
     // ---- timing
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> attn_ev;
@@ -517,6 +522,10 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
         CK(launch_rmsnorm(s, e->v_x, L.norm2, e->v_xn, N, E, c.v_rms_eps));
         CK(launch_gemm(s, e->v_xn, L.w13, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, E, c.v_intermediate, EPI_SWIGLU));
         CK(launch_gemm(s, e->v_act, L.w2, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, c.v_intermediate, E, EPI_RESIDUAL));
+        if (e->dbg_hidden && (size_t)(i + 1) * N * E <= e->dbg_cap) {
+            CK(hipMemcpyAsync(e->dbg_hidden + (size_t)i * N * E, e->v_x, (size_t)N * E * 2, hipMemcpyDeviceToDevice, s));
+            e->dbg_vit_rows = N;
+        }
     }
     const bf16_t* xin = e->v_x;
     if (c.v_post_norm) {
@@ -654,6 +663,11 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         CK(launch_rmsnorm(s, e->p_x, Lw.ln2, e->p_xn, T, H, c.rms_norm_eps));
         CK(launch_gemm(s, e->p_xn, Lw.w13, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, H, c.intermediate_size, EPI_SWIGLU));
         CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL));
+        const size_t voff = (size_t)c.v_layers * e->dbg_vit_rows * c.v_embed_dim;       // LM layers are stored behind the ViT blocks
+        if (e->dbg_hidden && voff + (size_t)(i + 1) * T * H <= e->dbg_cap) {
+            CK(hipMemcpyAsync(e->dbg_hidden + voff + (size_t)i * T * H, e->p_x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
+            e->dbg_lm_rows = T;
+        }
     }
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, slots ? e->p_dst : nullptr, e->d_h, B, H));
@@ -710,10 +724,7 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
     return DOTS_OK;
 }
 
-int splits_for_ctx(int max_ctx) {
-    const int pages = (max_ctx + 63) / 64;
-    return std::max(1, std::min((pages + 3) / 4, 64));
-}
+int splits_for_ctx(int max_ctx) { return decode_attn_splits(max_ctx); }
 
 double decode_step_bytes(const DotsConfig& c) {
     const double H = c.hidden_size, Nq = c.num_heads * 128.0, Nkv = c.num_kv_heads * 128.0, I = c.intermediate_size;
@@ -1147,6 +1158,34 @@ int dots_get_last_tokens(DotsEngine* e, int32_t* out) {
     CK(hipMemcpyAsync(ids.data(), e->out_ids, (size_t)e->B * e->out_cap * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipStreamSynchronize(e->stream));
     for (int b = 0; b < e->B; ++b) out[b] = lens[b] > 0 ? ids[(size_t)b * e->out_cap + lens[b] - 1] : -1;
+    return DOTS_OK;
+}
+
+int dots_debug_capture_hidden(DotsEngine* e, int64_t capacity_elems) {
+    if (!e || capacity_elems < 0) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(e->stream));
+    if (e->dbg_hidden) { e->release(e->dbg_hidden); e->dbg_hidden = nullptr; }
+    e->dbg_cap = 0; e->dbg_vit_rows = e->dbg_lm_rows = 0;
+    if (capacity_elems > 0) {
+        CK(e->alloc(&e->dbg_hidden, (size_t)capacity_elems));
+        e->dbg_cap = (size_t)capacity_elems;
+    }
+    return DOTS_OK;
+}
+
+int dots_debug_read_hidden(DotsEngine* e, int which, int layer, void* out_host, int64_t* rows_out) {
+    if (!e || !out_host || !rows_out || !e->dbg_hidden) return e ? e->fail(DOTS_E_STATE, "hidden-state capture is off") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    const DotsConfig& c = e->cfg;
+    const int64_t rows = which == 0 ? e->dbg_vit_rows : e->dbg_lm_rows;
+    const int dim = which == 0 ? c.v_embed_dim : c.hidden_size, n_layers = which == 0 ? c.v_layers : c.num_layers;
+    if (rows <= 0 || layer < 0 || layer >= n_layers) return e->fail(DOTS_E_INVALID, "no captured hidden state for layer %d", layer);
+    const size_t off = (which == 0 ? 0 : (size_t)c.v_layers * e->dbg_vit_rows * c.v_embed_dim) + (size_t)layer * rows * dim;
+    if (off + (size_t)rows * dim > e->dbg_cap) return e->fail(DOTS_E_CAPACITY, "capture buffer too small for layer %d", layer);
+    CK(hipMemcpyAsync(out_host, e->dbg_hidden + off, (size_t)rows * dim * 2, hipMemcpyDeviceToHost, e->stream));
+    CK(hipStreamSynchronize(e->stream));
+    *rows_out = rows;
     return DOTS_OK;
 }
 

@@ -53,6 +53,8 @@ hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w,
                              int B, int H, int I, float eps);
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, float* logits,
                              int B, int H, int V, float eps);
+int decode_attn_waves();                       // pages in flight per decode-attention workgroup (engine constant)
+int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
                               int B, int Hq, int Hkv, int n_splits, float scale);

@@ -80,6 +80,8 @@ def _prototypes(lib):
         "dots_get_last_tokens": (i32, [vp, P(i32)]),
         "dots_get_stats": (i32, [vp, P(CDotsStats)]),
         "dots_synchronize": (i32, [vp]),
+        "dots_debug_capture_hidden": (i32, [vp, i64]),
+        "dots_debug_read_hidden": (i32, [vp, i32, i32, vp, P(i64)]),
         "dots_dev_alloc": (i32, [vp, i64, P(vp)]),
         "dots_dev_free": (i32, [vp, vp]),
         "dots_memcpy_h2d": (i32, [vp, vp, vp, i64]),
@@ -109,7 +111,8 @@ EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
     "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_get_logits",
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release",
-    "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_dev_alloc",
+    "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
+    "dots_debug_read_hidden", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
     "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
@@ -354,6 +357,20 @@ class Engine:
                                         _i32p(out_ids), _i32p(out_lens)), "dots_generate")
         self._B = B
         return out_ids, out_lens
+
+    def capture_hidden(self, capacity_elems: int):
+        """Debug: keep the residual stream after every ViT block / LM prefill layer of the next calls (0 = off)."""
+        self._ck(self.lib.dots_debug_capture_hidden(self.h, int(capacity_elems)), "dots_debug_capture_hidden")
+
+    def read_hidden(self, which: str, layer: int) -> np.ndarray:
+        """which = "vit" | "lm" -> uint16 (raw bf16) [rows, dim] of that layer's output."""
+        dim = self.cfg.vision.embed_dim if which == "vit" else self.cfg.hidden_size
+        cap = (self.max_patches if which == "vit" else self.max_prefill_tokens) * dim
+        buf = np.empty(cap, dtype=np.uint16)
+        rows = C.c_int64(0)
+        self._ck(self.lib.dots_debug_read_hidden(self.h, 0 if which == "vit" else 1, int(layer), buf.ctypes.data_as(C.c_void_p), C.byref(rows)),
+                 "dots_debug_read_hidden")
+        return buf[: rows.value * dim].reshape(rows.value, dim).copy()
 
     def stats(self) -> dict:
         st = CDotsStats()

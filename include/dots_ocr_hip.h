@@ -159,6 +159,11 @@ int dots_set_next_tokens(DotsEngine* e, const int32_t* tokens_host, int B);
 /* Tokens chosen by the most recent prefill/decode step, int32 [B]. */
 int dots_get_last_tokens(DotsEngine* e, int32_t* out_host);
 int dots_get_stats(DotsEngine* e, DotsStats* out);
+/* Debug / parity tooling (tools/layer_error_trace.py): keep a copy of the bf16 residual stream after every ViT block and every
+ * LM prefill layer of the following dots_vit_forward / dots_prefill calls.  capacity_elems = 0 switches the capture off.
+ * dots_debug_read_hidden: which = 0 ViT block `layer` -> [patches, v_embed_dim], which = 1 LM layer `layer` -> [tokens, hidden]. */
+int dots_debug_capture_hidden(DotsEngine* e, int64_t capacity_elems);
+int dots_debug_read_hidden(DotsEngine* e, int which, int layer, void* out_host, int64_t* rows_out);
 int dots_synchronize(DotsEngine* e);
 
 /* ---- device memory helpers (so a binding needs no other GPU library) ------------------- */

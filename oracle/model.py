@@ -18,7 +18,9 @@ What it restates (plain PyTorch on CPU, functional over an HF-named state dict):
     PARITY UNPINNED for the tower as a whole (no golden vectors exist anywhere in the reference).
     Its building blocks ARE pinned against the in-container transformers analogues: 2-D rope
     position ids (vision_utils.py:81-127), VisionRotaryEmbedding + apply_rotary_pos_emb_vision
-    (modeling_qwen2_vl.py:225-248), PatchMerger (modeling_qwen2_vl.py:277-290).
+    (modeling_qwen2_vl.py:225-248), PatchMerger (modeling_qwen2_vl.py:277-290), and one whole
+    transformer BLOCK (norm order, residual placement, qkv split, rope, per-image attention, SwiGLU
+    wiring) against Qwen2_5_VLVisionBlock (modeling_qwen2_5_vl.py) on shared weights.
 
 Two numeric modes:
   emulate_bf16=False  fp32 activations (bf16-valued weights): the truth for logit tolerances.
@@ -111,6 +113,37 @@ def _attention(q, k, v, scale: float, causal: bool, emu: bool, q_chunk: int = 20
     return _r(out, emu)
 
 
+def vision_block(sd: SD, p: str, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, seqlens, n_heads: int, head_dim: int,
+                 eps: float, emu: bool) -> torch.Tensor:
+    """One pre-norm transformer block of the vision tower on packed patches x [N, E] (cos/sin [N, 1, head_dim]):
+         x += proj(attention(rope(qkv(rmsnorm1(x)))))      bidirectional, one sequence per image
+         x += fc2(silu(fc1(rmsnorm2(x))) * fc3(rmsnorm2(x)))
+    Biases are used when the state dict has them.  PINNED (tests/test_oracle_pins.py) against the in-container
+    transformers Qwen2_5_VLVisionBlock — the same composition with fc1/fc3/fc2 = gate/up/down — on shared weights."""
+    E = n_heads * head_dim
+    scale = 1.0 / math.sqrt(head_dim)
+    h = rms_norm(x, _w(sd, p + "norm1.weight"), eps, emu)
+    qb = sd.get(p + "attn.qkv.bias")
+    qkv = _r(linear(h, _w(sd, p + "attn.qkv.weight"), None if qb is None else qb.float()), emu)
+    q, k, vv = qkv.view(-1, 3, n_heads, head_dim).unbind(1)    # [N,H,D]
+    q = _r(q * cos + rotate_half(q) * sin, emu)
+    k = _r(k * cos + rotate_half(k) * sin, emu)
+    att = torch.empty_like(q)
+    s0 = 0
+    for n in seqlens:
+        att[s0:s0 + n] = _attention(q[s0:s0 + n].transpose(0, 1), k[s0:s0 + n].transpose(0, 1),
+                                    vv[s0:s0 + n].transpose(0, 1), scale, False, emu).transpose(0, 1)
+        s0 += n
+    pb = sd.get(p + "attn.proj.bias")
+    x = _r(x + linear(att.reshape(-1, E), _w(sd, p + "attn.proj.weight"), None if pb is None else pb.float()), emu)
+    h = rms_norm(x, _w(sd, p + "norm2.weight"), eps, emu)
+    b1, b2, b3 = (sd.get(p + f"mlp.fc{j}.bias") for j in (1, 2, 3))
+    g = linear(h, _w(sd, p + "mlp.fc1.weight"), None if b1 is None else b1.float())
+    u = linear(h, _w(sd, p + "mlp.fc3.weight"), None if b3 is None else b3.float())
+    a = _r(F.silu(g) * u, emu)                     # fused epilogue: one rounding
+    return _r(x + linear(a, _w(sd, p + "mlp.fc2.weight"), None if b2 is None else b2.float()), emu)
+
+
 def vision_tower(sd: SD, cfg, pixel_values: torch.Tensor, grid_thw: torch.Tensor,
                  emulate_bf16: bool = False, return_hidden: bool = False):
     """pixel_values [N, C*T*P*P] f32, grid_thw [n_img, 3] -> merged embeddings [N/merge^2, hidden]."""
@@ -132,27 +165,7 @@ def vision_tower(sd: SD, cfg, pixel_values: torch.Tensor, grid_thw: torch.Tensor
     scale = 1.0 / math.sqrt(D)
     hiddens = []
     for i in range(v.num_hidden_layers):
-        p = f"{pre}blocks.{i}."
-        h = rms_norm(x, _w(sd, p + "norm1.weight"), v.rms_norm_eps, emu)
-        qb = sd.get(p + "attn.qkv.bias")
-        qkv = _r(linear(h, _w(sd, p + "attn.qkv.weight"), None if qb is None else qb.float()), emu)
-        q, k, vv = qkv.view(-1, 3, Hh, D).unbind(1)    # [N,H,D]
-        q = _r(q * cos + rotate_half(q) * sin, emu)
-        k = _r(k * cos + rotate_half(k) * sin, emu)
-        att = torch.empty_like(q)
-        s0 = 0
-        for n in seqlens:
-            att[s0:s0 + n] = _attention(q[s0:s0 + n].transpose(0, 1), k[s0:s0 + n].transpose(0, 1),
-                                        vv[s0:s0 + n].transpose(0, 1), scale, False, emu).transpose(0, 1)
-            s0 += n
-        pb = sd.get(p + "attn.proj.bias")
-        x = _r(x + linear(att.reshape(-1, E), _w(sd, p + "attn.proj.weight"), None if pb is None else pb.float()), emu)
-        h = rms_norm(x, _w(sd, p + "norm2.weight"), v.rms_norm_eps, emu)
-        b1, b2, b3 = (sd.get(p + f"mlp.fc{j}.bias") for j in (1, 2, 3))
-        g = linear(h, _w(sd, p + "mlp.fc1.weight"), None if b1 is None else b1.float())
-        u = linear(h, _w(sd, p + "mlp.fc3.weight"), None if b3 is None else b3.float())
-        a = _r(F.silu(g) * u, emu)                     # fused epilogue: one rounding
-        x = _r(x + linear(a, _w(sd, p + "mlp.fc2.weight"), None if b2 is None else b2.float()), emu)
+        x = vision_block(sd, f"{pre}blocks.{i}.", x, cos, sin, seqlens, Hh, D, v.rms_norm_eps, emu)
         if return_hidden:
             hiddens.append(x.clone())
     if v.post_norm:

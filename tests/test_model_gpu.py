@@ -361,3 +361,48 @@ def test_parser_pipelines_a_document_over_the_engine_slots(tmp_path):
         assert Path(one["md_content_path"]).read_text() == Path(piped[i]["md_content_path"]).read_text(), i
         assert (one["input_height"], one["input_width"]) == (piped[i]["input_height"], piped[i]["input_width"])
     model.engine.close()
+
+
+def test_from_pretrained_checkpoint_directory_to_tokens(tmp_path):
+    """SURVEY §8 a1 (reference dots_ocr/parser.py:62-76): a checkpoint DIRECTORY (config.json with vision_config,
+    preprocessor_config.json, generation_config.json, sharded *.safetensors) -> DotsOCRParser(use_hf=True) ->
+    from_pretrained -> HIP engine -> tokens, equal to what the CPU oracle decodes from the same files."""
+    import json
+    from dots_ocr.parser import DotsOCRParser
+    from dots_ocr_amd.synthetic import synth_page
+    from dots_ocr_amd.weights import load_state_dict, save_safetensors
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=31)
+    v = cfg.vision
+    (tmp_path / "config.json").write_text(json.dumps({
+        "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers, "num_attention_heads": cfg.num_attention_heads,
+        "num_key_value_heads": cfg.num_key_value_heads, "intermediate_size": cfg.intermediate_size, "vocab_size": cfg.vocab_size,
+        "rope_theta": cfg.rope_theta, "rms_norm_eps": cfg.rms_norm_eps, "image_token_id": cfg.image_token_id, "attention_bias": True,
+        "tie_word_embeddings": False, "pad_token_id": cfg.pad_token_id,
+        "vision_config": {"embed_dim": v.embed_dim, "num_hidden_layers": v.num_hidden_layers, "num_attention_heads": v.num_attention_heads,
+                          "intermediate_size": v.intermediate_size, "patch_size": 14, "spatial_merge_size": 2, "hidden_size": v.hidden_size}}))
+    (tmp_path / "generation_config.json").write_text(json.dumps({"eos_token_id": list(cfg.eos_token_ids), "do_sample": False}))
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"min_pixels": 3136, "max_pixels": 11289600}))
+    names = sorted(sd)
+    save_safetensors({k: sd[k] for k in names[: len(names) // 2]}, tmp_path / "model-00001-of-00002.safetensors")      # two shards
+    save_safetensors({k: sd[k] for k in names[len(names) // 2:]}, tmp_path / "model-00002-of-00002.safetensors")
+    parser = DotsOCRParser(use_hf=True, model_path=str(tmp_path), output_dir=str(tmp_path / "out"), hf_max_new_tokens=12)
+    page = synth_page(5, (196, 140))
+    text = parser._inference_with_hf(page, "Extract the text content from this image.")
+    assert isinstance(text, str)
+    # the same call sequence by hand, to get at the token ids
+    proc, model = parser.processor, parser.model
+    inputs = parser._build_inputs([page], ["Extract the text content from this image."])
+    out = model.generate(**inputs, max_new_tokens=12)
+    new = out[0, inputs["input_ids"].shape[1]:].tolist()
+    assert proc.batch_decode([new])[0] == text
+    sd_back = load_state_dict(tmp_path)
+    ids = inputs["input_ids"][0]
+    toks, lgs = om.generate(sd_back, model.config, ids.cpu(), inputs["pixel_values"].cpu(), inputs["image_grid_thw"].cpu(), len(new),
+                            emulate_bf16=True, forced_tokens=new, return_logits=True)
+    for step, (tok, lg) in enumerate(zip(new, lgs)):
+        best = int(torch.argmax(lg))
+        assert tok == best or float(lg[best] - lg[tok]) < 0.03 * float(lg.max() - lg.min()), (step, tok, best)
+        if tok in cfg.eos_token_ids:
+            break
+    model.engine.close()

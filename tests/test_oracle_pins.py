@@ -167,3 +167,47 @@ def test_fixed_point_bicubic_restatement_is_bit_exact_with_pillow():
         img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
         ref = np.asarray(img.resize((rw, rh), resample=Image.BICUBIC))
         assert np.array_equal(oip.pil_bicubic_resize(np.asarray(img), rw, rh), ref), (w, h, rw, rh)
+
+
+def test_vision_block_composition_matches_transformers_qwen2_5_vl_block():
+    """One whole transformer block of the oracle's vision tower == the in-container transformers Qwen2_5_VLVisionBlock on
+    shared weights: RMSNorm -> qkv(+bias) -> 2-D rope -> per-image bidirectional attention -> proj -> +res -> RMSNorm ->
+    SwiGLU(gate, up -> down) -> +res.  This pins the block COMPOSITION (norm order, residual placement, qkv split order,
+    rotate_half convention, var-len attention boundaries, SwiGLU wiring), which VERDICT r1 flagged as recollection-only;
+    dots.ocr's own block (HF-hub remote code, absent offline) is recalled to differ from it only in bias-free linears and
+    eps, both of which oracle.vision_block reads from the state dict / config."""
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLVisionBlock
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import VisionRotaryEmbedding
+    from transformers.vision_utils import get_vision_position_ids
+    torch.manual_seed(3)
+    E, Hh, I = 256, 2, 384
+    vc = Qwen2_5_VLVisionConfig(hidden_size=E, num_heads=Hh, intermediate_size=I, depth=1, hidden_act="silu", out_hidden_size=E)
+    vc._attn_implementation = "sdpa"
+    blk = Qwen2_5_VLVisionBlock(vc).eval().float()
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.05 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 and prm.shape[0] == E and prm is blk.norm1.weight else 0.0))
+    hf = blk.state_dict()
+    sd = {"b.norm1.weight": hf["norm1.weight"], "b.norm2.weight": hf["norm2.weight"],
+          "b.attn.qkv.weight": hf["attn.qkv.weight"], "b.attn.qkv.bias": hf["attn.qkv.bias"],
+          "b.attn.proj.weight": hf["attn.proj.weight"], "b.attn.proj.bias": hf["attn.proj.bias"],
+          "b.mlp.fc1.weight": hf["mlp.gate_proj.weight"], "b.mlp.fc1.bias": hf["mlp.gate_proj.bias"],
+          "b.mlp.fc3.weight": hf["mlp.up_proj.weight"], "b.mlp.fc3.bias": hf["mlp.up_proj.bias"],
+          "b.mlp.fc2.weight": hf["mlp.down_proj.weight"], "b.mlp.fc2.bias": hf["mlp.down_proj.bias"]}
+    grid = torch.tensor([[1, 4, 6], [1, 2, 8], [1, 2, 2]])                     # three images of 24, 16 and 4 patches
+    lens = (grid[:, 1] * grid[:, 2]).tolist()
+    n = sum(lens)
+    x = torch.randn(n, E)
+    D = E // Hh
+    freqs = VisionRotaryEmbedding(D // 2)(get_vision_position_ids(grid, 2))
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    with torch.no_grad():
+        ref = blk(x, cu_seqlens=cu, position_embeddings=(emb.cos(), emb.sin()))
+    cos, sin = om.vision_rope_cos_sin(grid, D, 2)
+    got = om.vision_block(sd, "b.", x, cos.unsqueeze(1), sin.unsqueeze(1), lens, Hh, D, 1e-6, False)
+    assert torch.allclose(got, ref, atol=2e-5), (got - ref).abs().max()
+    # attention really is per image: moving the image boundaries changes the result
+    other = om.vision_block(sd, "b.", x, cos.unsqueeze(1), sin.unsqueeze(1), [n], Hh, D, 1e-6, False)
+    assert (other - ref).abs().max() > 1e-3

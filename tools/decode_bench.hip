@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
     dots_trace_set_decode(g_trace);
 #endif
     const int max_pages = (max_seq + 63) / 64;
-    const int n_splits = std::max(1, std::min((max_pages + 3) / 4, 64));
+    const int n_splits = decode_attn_splits(max_seq);
     // weights: 0x3c3c = bf16 0.0115
     std::vector<bf16_t*> qkv(L), o(L), w13(L), down(L), ln1(L), ln2(L), bias(L);
     for (int i = 0; i < L; ++i) {
@@ -146,6 +146,11 @@ int main(int argc, char** argv) {
     const double kv_bytes = (double)B * (ctx + 1) * L * Hkv * 128 * 2 * 2;
     printf("decode_bench: B=%d ctx=%d max_seq_len=%d (n_splits %d); algorithmic bytes/step %.1f MB weights + %.1f MB KV\n", B, ctx, max_seq, n_splits,
            w_bytes / 1e6, kv_bytes / 1e6);
+    if (argc > 4) {            // "once": a few plain replays of the whole step and nothing else (rocprofv3 --pmc runs: tools/pmc_decode.sh)
+        const double t = time_graph(step, 2);
+        printf("whole step %.1f us (3 replays under the profiler)\n", t);
+        return 0;
+    }
     const double t_step = time_graph(step);
     printf("whole step              %9.1f us   %.2f TB/s algorithmic (%.1f %% of 8 TB/s)\n", t_step, (w_bytes + kv_bytes) / t_step / 1e6,
            (w_bytes + kv_bytes) / t_step / 1e6 / 8 * 100);
