@@ -18,7 +18,9 @@ class HipEngineUnavailable(RuntimeError):
 
 
 def lib_path() -> Path:
-    return Path(__file__).resolve().parent / "lib" / "libdots_ocr_hip.so"
+    """The in-tree build; DOTS_OCR_LIB points at another build of the same library (A/B runs of kernel variants)."""
+    override = os.environ.get("DOTS_OCR_LIB")
+    return Path(override) if override else Path(__file__).resolve().parent / "lib" / "libdots_ocr_hip.so"
 
 
 def load() -> ctypes.CDLL:

@@ -238,6 +238,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
         // every share is in LDS one barrier before the first MFMA block that reads it, and a buffer is overwritten only
         // after both halves' PV of the tile it held.
         const bool late = w >= NW / 2;                   // wave-uniform
+        // Static priority for the later-dispatched half (guide "Two waves per SIMD" item 4): waves 4-7 lose VALU arbitration
+        // to their older SIMD partners on every segment; one s_setprio before the loop, no per-segment flips.
+        // DOTS_FLASH_PRIO (compile-time, tools/build_variant.sh) switches it for A/B runs.
+#ifndef DOTS_FLASH_PRIO
+#define DOTS_FLASH_PRIO 1
+#endif
+        if (DOTS_FLASH_PRIO && late) __builtin_amdgcn_s_setprio(1);
         load_k(0);
         load_v(0);
         write_k(0);

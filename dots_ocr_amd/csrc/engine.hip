@@ -131,8 +131,11 @@ struct DotsEngine {
     std::vector<QBlock> hp_qblocks;
 
     // ---- KV pool + decode state
-    int max_pages = 0;                     // per sequence
-    bf16_t* pool = nullptr;                // [layers][max_batch*max_pages][Hkv][2][8192]
+    int max_pages = 0;                     // block-table width: pages of one sequence at max_seq_len
+    int n_pool_pages = 0;                  // allocatable pages; page n_pool_pages is the scratch page idle rows write to
+    std::vector<int32_t> free_pages;       // LIFO free list
+    std::vector<std::vector<int32_t>> slot_pages;
+    bf16_t* pool = nullptr;                // [layers][n_pool_pages + 1][Hkv][2][8192]
     size_t pool_layer_elems = 0;
     int32_t *block_table = nullptr, *ctx_len = nullptr, *cur_tokens = nullptr, *out_ids = nullptr, *out_lens = nullptr,
             *finished = nullptr, *eos_ids = nullptr, *am_idx = nullptr;
@@ -153,7 +156,9 @@ struct DotsEngine {
     int slot_limit[16] = {0};              // prompt length + generation cap of the slot's sequence
     int32_t *d_sel = nullptr, *d_sel_new = nullptr, *d_max_len = nullptr, *p_dst = nullptr;
     const int32_t* sel_now = nullptr;      // selection mask of the next select_tokens() call
-    struct StepGraph { int rows, splits; hipGraph_t graph; hipGraphExec_t exec; };
+    // captured decode steps, keyed by everything the capture bakes in: rows, KV splits, static batch (out_cap = row stride of
+    // the output buffer) or slot mode (out_cap = 0), number of EOS ids; sampling changes drop the cache (dots_set_sampling)
+    struct StepGraph { int rows, splits, out_cap, n_eos; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<StepGraph> step_graphs;
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
@@ -404,7 +409,12 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->p_qblocks, (size_t)(e->TP / 128 + c.max_batch + 1) * c.num_heads));
 
     e->max_pages = (c.max_seq_len + 63) / 64;
-    e->pool_layer_elems = (size_t)c.max_batch * e->max_pages * c.num_kv_heads * 2 * 8192;
+    // paged KV: a pool of 64-token pages shared by all sequence slots; a sequence reserves ceil((prompt + generation cap) / 64)
+    // pages when it is prefilled and returns them when its slot is released (kv_pool_tokens = 0: room for max_batch sequences
+    // of max_seq_len, i.e. no sequence can ever be refused for lack of pages)
+    const int64_t pool_tokens = c.kv_pool_tokens > 0 ? c.kv_pool_tokens : (int64_t)c.max_batch * e->max_pages * 64;
+    e->n_pool_pages = (int)((pool_tokens + 63) / 64);
+    e->pool_layer_elems = (size_t)(e->n_pool_pages + 1) * c.num_kv_heads * 2 * 8192;
     CK(e->alloc(&e->pool, e->pool_layer_elems * c.num_layers));
     const int mb = std::max(c.max_batch, 16);
     CK(e->alloc(&e->block_table, (size_t)mb * e->max_pages));
@@ -427,14 +437,40 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_logits, (size_t)16 * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)16 * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)16 * c.num_heads * 64 * 2));
-    // identity paging: sequence slot b owns pages [b*max_pages, (b+1)*max_pages)
-    e->hp_table.resize((size_t)mb * e->max_pages);
-    for (int b = 0; b < mb; ++b)
-        for (int p = 0; p < e->max_pages; ++p) e->hp_table[(size_t)b * e->max_pages + p] = (b % c.max_batch) * e->max_pages + p;
+    // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
+    // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
+    e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
+    e->slot_pages.assign(mb, {});
+    e->free_pages.resize(e->n_pool_pages);
+    for (int p = 0; p < e->n_pool_pages; ++p) e->free_pages[p] = e->n_pool_pages - 1 - p;      // pop_back hands out page 0 first
     CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, e->stream));
     for (auto& ev : e->ev) CK(hipEventCreate(&ev));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
+}
+
+// ---- KV page allocator (host side; the kernels only ever see the block table)
+hipError_t upload_table_row(DotsEngine* e, int slot) {
+    return hipMemcpyAsync(e->block_table + (size_t)slot * e->max_pages, e->hp_table.data() + (size_t)slot * e->max_pages, (size_t)e->max_pages * 4,
+                          hipMemcpyHostToDevice, e->stream);
+}
+void release_pages(DotsEngine* e, int slot) {
+    auto& mine = e->slot_pages[slot];
+    for (auto it = mine.rbegin(); it != mine.rend(); ++it) e->free_pages.push_back(*it);
+    mine.clear();
+    std::fill(e->hp_table.begin() + (size_t)slot * e->max_pages, e->hp_table.begin() + (size_t)(slot + 1) * e->max_pages, e->n_pool_pages);
+}
+// pages for `tokens` positions of the sequence in `slot` (it holds none yet); false: the pool cannot serve them
+bool reserve_pages(DotsEngine* e, int slot, int tokens) {
+    const int need = (tokens + 63) / 64;
+    if (need > (int)e->free_pages.size() || need > e->max_pages) return false;
+    auto& mine = e->slot_pages[slot];
+    for (int p = 0; p < need; ++p) {
+        mine.push_back(e->free_pages.back());
+        e->free_pages.pop_back();
+        e->hp_table[(size_t)slot * e->max_pages + p] = mine.back();
+    }
+    return true;
 }
 
 // sequences -> 64-token tiles and 128-row query blocks
@@ -621,8 +657,22 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), 16 * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_tiles, e->hp_tiles.data(), e->hp_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_qblocks, e->hp_qblocks.data(), e->hp_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
+    // ---- KV pages: a static batch resets every slot; a slot prefill reserves for its own sequences only
+    if (!slots)
+        for (int b = 0; b < (int)e->slot_pages.size(); ++b) release_pages(e, b);
+    {
+        int need = 0;
+        for (int b = 0; b < B; ++b) need += (std::min(L[b] + (slots ? max_new[b] : e->out_cap), c.max_seq_len) + 63) / 64;
+        if (need > (int)e->free_pages.size()) {
+            const int have = (int)e->free_pages.size();
+            if (!slots) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
+            return e->fail(DOTS_E_CAPACITY, "KV pool exhausted: these sequences need %d pages of 64 tokens, %d of %d are free", need, have, e->n_pool_pages);
+        }
+        for (int b = 0; b < B; ++b) reserve_pages(e, S[b], std::min(L[b] + (slots ? max_new[b] : e->out_cap), c.max_seq_len));
+        if (!slots) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
+        else for (int b = 0; b < B; ++b) CK(upload_table_row(e, S[b]));
+    }
     if (!slots) {
-        if (e->slot_mode) drop_step_graphs(e);
         e->slot_mode = false;
         std::fill(e->slot_active, e->slot_active + 16, 0);
         CK(hipMemcpyAsync(e->ctx_len, lens, B * 4, hipMemcpyHostToDevice, s));
@@ -726,6 +776,23 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
 
 int splits_for_ctx(int max_ctx) { return decode_attn_splits(max_ctx); }
 
+// The captured decode step for (rows = e->B, splits, out_cap, e->n_eos): looked up in the cache or captured now.
+int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_t* exec) {
+    for (auto& g : e->step_graphs)
+        if (g.rows == rows && g.splits == n_splits && g.out_cap == out_cap && g.n_eos == e->n_eos) { *exec = g.exec; return DOTS_OK; }
+    if (e->step_graphs.size() >= 32) drop_step_graphs(e);
+    DotsEngine::StepGraph g{rows, n_splits, out_cap, e->n_eos, nullptr, nullptr};
+    CK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int r = decode_step_launches(e, n_splits);
+    hipError_t ce = hipStreamEndCapture(e->stream, &g.graph);
+    if (r != DOTS_OK) return r;
+    CK(ce);
+    CK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    e->step_graphs.push_back(g);
+    *exec = g.exec;
+    return DOTS_OK;
+}
+
 double decode_step_bytes(const DotsConfig& c) {
     const double H = c.hidden_size, Nq = c.num_heads * 128.0, Nkv = c.num_kv_heads * 128.0, I = c.intermediate_size;
     const double per_layer = H * (Nq + 2 * Nkv) + (c.attention_bias ? Nq + 2 * Nkv : 0) + Nq * H + 3 * H * I + 2 * H;
@@ -773,6 +840,7 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
     if (c.num_heads * 128 < 512 || c.intermediate_size < 512) return bad("projection K too small for the 16-way in-workgroup split");
     if (c.max_batch < 1 || c.max_batch > 16) return bad("max_batch must be in [1,16]");
     if (c.max_seq_len < 64 || c.max_patches < 4 || c.max_prefill_tokens < 1) return bad("capacity fields too small");
+    if (c.kv_pool_tokens < 0 || (c.kv_pool_tokens > 0 && c.kv_pool_tokens < 64)) return bad("kv_pool_tokens must be 0 (default) or >= 64");
     if (c.v_merge < 1 || c.v_temporal_patch != 1) return bad("unsupported vision patching");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "no such HIP device"; return DOTS_E_HIP; }
@@ -895,16 +963,8 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     CK(hipEventRecord(e->ev[4], s));
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);       // engine constant: results do not depend on the batch
     const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
-    hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    if (use_graph && max_new_tokens > 1) {
-        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = decode_step_launches(e, n_splits);
-        hipError_t ce = hipStreamEndCapture(s, &graph);
-        if (r != DOTS_OK) return r;
-        CK(ce);
-        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    }
+    if (use_graph && max_new_tokens > 1) RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
     std::vector<int32_t> fin(16);
     int steps = 0;
     for (int step = 1; step < max_new_tokens; ++step) {
@@ -927,8 +987,6 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     CK(hipMemcpyAsync(out_lens, e->out_lens, B * 4, hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
     std::memcpy(out_ids, tmp.data(), tmp.size() * 4);
-    if (exec) hipGraphExecDestroy(exec);
-    if (graph) hipGraphDestroy(graph);
 
     // ---- stats
     e->stats.decode_steps = steps;
@@ -951,7 +1009,6 @@ int dots_set_eos(DotsEngine* e, const int32_t* eos_ids, int n_eos) {
     CK(hipSetDevice(e->device));
     if (n_eos) CK(hipMemcpyAsync(e->eos_ids, eos_ids, n_eos * 4, hipMemcpyHostToDevice, e->stream));
     CK(hipStreamSynchronize(e->stream));
-    if (n_eos != e->n_eos) drop_step_graphs(e);
     e->n_eos = n_eos;
     return DOTS_OK;
 }
@@ -986,20 +1043,8 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     static const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
-        for (auto& g : e->step_graphs)
-            if (g.rows == rows && g.splits == n_splits) exec = g.exec;
-        if (!exec) {
-            if (e->step_graphs.size() >= 32) drop_step_graphs(e);
-            DotsEngine::StepGraph g{rows, n_splits, nullptr, nullptr};
-            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            int r = decode_step_launches(e, n_splits);
-            hipError_t ce = hipStreamEndCapture(s, &g.graph);
-            if (r != DOTS_OK) { e->B = 0; return r; }
-            CK(ce);
-            CK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-            e->step_graphs.push_back(g);
-            exec = g.exec;
-        }
+        int r = step_graph(e, rows, n_splits, 0, &exec);
+        if (r != DOTS_OK) { e->B = 0; return r; }
     }
     int r = DOTS_OK;
     for (int i = 0; i < n_steps && r == DOTS_OK; ++i) {
@@ -1045,7 +1090,16 @@ int dots_slot_release(DotsEngine* e, int slot) {
     CK(hipSetDevice(e->device));
     e->slot_active[slot] = 0;
     e->sel_dirty = true;
-    CK(hipMemsetAsync(e->ctx_len + slot, 0, 4, e->stream));          // an idle row attends over one key only
+    CK(hipMemsetAsync(e->ctx_len + slot, 0, 4, e->stream));          // an idle row attends over one key only ...
+    release_pages(e, slot);                                          // ... of the scratch page: its own pages go back to the pool
+    CK(upload_table_row(e, slot));
+    return DOTS_OK;
+}
+
+int dots_kv_pool_info(DotsEngine* e, int32_t* total_pages, int32_t* free_pages) {
+    if (!e || !total_pages || !free_pages) return DOTS_E_INVALID;
+    *total_pages = e->n_pool_pages;
+    *free_pages = (int32_t)e->free_pages.size();
     return DOTS_OK;
 }
 

@@ -28,7 +28,7 @@ class CDotsConfig(C.Structure):
         ("v_rms_eps", C.c_float), ("v_ln_eps", C.c_float),
         ("v_use_bias", C.c_int32), ("v_post_norm", C.c_int32),
         ("max_batch", C.c_int32), ("max_seq_len", C.c_int32),
-        ("max_patches", C.c_int64), ("max_prefill_tokens", C.c_int64),
+        ("max_patches", C.c_int64), ("max_prefill_tokens", C.c_int64), ("kv_pool_tokens", C.c_int64),
     ]
 
 
@@ -75,6 +75,7 @@ def _prototypes(lib):
         "dots_slots_poll": (i32, [vp, P(i32), P(i32)]),
         "dots_slot_read": (i32, [vp, i32, P(i32), i32, P(i32)]),
         "dots_slot_release": (i32, [vp, i32]),
+        "dots_kv_pool_info": (i32, [vp, P(i32), P(i32)]),
         "dots_get_logits": (i32, [vp, P(f32)]),
         "dots_set_next_tokens": (i32, [vp, P(i32), i32]),
         "dots_get_last_tokens": (i32, [vp, P(i32)]),
@@ -110,7 +111,7 @@ def _prototypes(lib):
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
     "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_get_logits",
-    "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release",
+    "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
@@ -119,7 +120,7 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int, max_prefill_tokens: int) -> CDotsConfig:
+def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int, max_prefill_tokens: int, kv_pool_tokens: int = 0) -> CDotsConfig:
     v = cfg.vision
     return CDotsConfig(
         hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers, num_heads=cfg.num_attention_heads,
@@ -131,7 +132,7 @@ def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int
         v_channels=v.num_channels, v_temporal_patch=v.temporal_patch_size, v_rms_eps=v.rms_norm_eps,
         v_ln_eps=v.merger_ln_eps, v_use_bias=int(v.use_bias), v_post_norm=int(v.post_norm),
         max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches,
-        max_prefill_tokens=max_prefill_tokens)
+        max_prefill_tokens=max_prefill_tokens, kv_pool_tokens=kv_pool_tokens)
 
 
 def _i32p(a: np.ndarray):
@@ -146,7 +147,7 @@ class Engine:
     """One GPU, one HIP stream, one model replica."""
 
     def __init__(self, cfg: DotsConfig, device: int = 0, max_batch: int = 8, max_seq_len: int = 8192,
-                 max_patches: int = 8 * 19824 + 64, max_prefill_tokens: Optional[int] = None):
+                 max_patches: int = 8 * 19824 + 64, max_prefill_tokens: Optional[int] = None, kv_pool_tokens: int = 0):
         self.lib = _lib.load()
         _prototypes(self.lib)
         self.cfg = cfg
@@ -157,7 +158,8 @@ class Engine:
         if max_prefill_tokens is None:
             max_prefill_tokens = max_batch * max_seq_len
         self.max_prefill_tokens = max_prefill_tokens
-        self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens)
+        self.kv_pool_tokens = kv_pool_tokens
+        self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens, kv_pool_tokens)
         h = C.c_void_p()
         rc = self.lib.dots_create(C.byref(self._cc), device, C.byref(h))
         if rc != 0:
@@ -314,6 +316,12 @@ class Engine:
 
     def slot_release(self, slot: int):
         self._ck(self.lib.dots_slot_release(self.h, int(slot)), "dots_slot_release")
+
+    def kv_pool_info(self):
+        """(total, free) pages of 64 tokens in the paged KV pool."""
+        tot, free = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.dots_kv_pool_info(self.h, C.byref(tot), C.byref(free)), "dots_kv_pool_info")
+        return int(tot.value), int(free.value)
 
     def get_logits(self) -> np.ndarray:
         out = np.empty((self._B, self.cfg.vocab_size), dtype=np.float32)

@@ -84,11 +84,18 @@ class ContinuousBatcher:
         Lowest slots first, so the decode graph covers as few rows as possible."""
         free = self.free_slots()
         group, patches, tokens = [], 0, 0
+        pages_free = self.engine.kv_pool_info()[1] if hasattr(self.engine, "kv_pool_info") else 1 << 30
         while self.pending and free:
             rid, req = self.pending[0]
             p, t = req.n_patches(), int(req.input_ids.shape[0])
             if group and (patches + p > self.max_patches or tokens + t > self.max_prefill_tokens):
                 break
+            need = (min(t + int(req.max_new_tokens), self.max_seq_len) + 63) // 64      # paged KV: prompt + generation cap, in 64-token pages
+            if need > pages_free:
+                if not group and not self.running:
+                    raise ValueError(f"request needs {need} KV pages, the pool holds {self.engine.kv_pool_info()[0]}")
+                break                                                                    # wait for a running sequence to return its pages
+            pages_free -= need
             self.pending.popleft()
             group.append((free.pop(0), rid, req))
             patches += p

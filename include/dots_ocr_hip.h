@@ -56,6 +56,8 @@ typedef struct DotsConfig {
     int32_t max_seq_len;      /* prompt + generated tokens per sequence */
     int64_t max_patches;      /* vision patches per dots_vit_forward call (workspace) */
     int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
+    int64_t kv_pool_tokens;   /* paged KV cache: tokens the page pool holds across ALL sequences (pages of 64); a sequence reserves
+                                 prompt + generation cap when it is prefilled.  0 = max_batch * max_seq_len (never refuses) */
 } DotsConfig;
 
 /* Per-phase device time of the last dots_generate / dots_vit_forward / ... call, measured with
@@ -151,6 +153,9 @@ int dots_slots_decode(DotsEngine* e, int n_steps);
 int dots_slots_poll(DotsEngine* e, int32_t* finished_host, int32_t* out_lens_host);
 int dots_slot_read(DotsEngine* e, int slot, int32_t* out_ids_host, int capacity, int32_t* n_out);
 int dots_slot_release(DotsEngine* e, int slot);
+/* Paged KV pool: pages of 64 tokens in total / currently free (an admission policy checks this before dots_slots_prefill,
+ * which refuses with DOTS_E_CAPACITY when prompt + max_new_tokens of the new sequences do not fit). */
+int dots_kv_pool_info(DotsEngine* e, int32_t* total_pages, int32_t* free_pages);
 
 /* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
 int dots_get_logits(DotsEngine* e, float* out_host);

@@ -406,3 +406,44 @@ def test_from_pretrained_checkpoint_directory_to_tokens(tmp_path):
         if tok in cfg.eos_token_ids:
             break
     model.engine.close()
+
+
+def test_paged_kv_pool_is_shared_and_recycled(setup):
+    """north_star "paged KV": the cache is a pool of 64-token pages shared by the slots, a sequence reserves prompt +
+    generation cap when it is prefilled and returns the pages at release.  An engine whose pool (16 pages = 1 024 tokens) is far
+    smaller than slots x max_seq_len (4 x 640) still serves 9 requests through continuous batching with the same tokens as
+    the default engine, never holds more pages than the pool, ends with every page free, and refuses what cannot fit."""
+    from dots_ocr_amd.engine import DotsEngineError, Engine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg, sd, eng = setup
+    small = Engine(cfg, max_batch=4, max_seq_len=640, max_patches=4096, max_prefill_tokens=2048, kv_pool_tokens=1024)
+    small.load_state_dict(sd)
+    assert small.kv_pool_info() == (16, 16)
+    grids = [(1, 4, 6), (1, 6, 6), (1, 4, 4), (1, 8, 4), (1, 4, 4), (1, 6, 4), (1, 4, 6), (1, 4, 8), (1, 6, 4)]
+    caps = [70, 130, 5, 200, 64, 90, 33, 120, 150]
+    reqs, singles = [], []
+    for i, (g, cap) in enumerate(zip(grids, caps)):
+        pv, grid, seqs = _inputs(cfg, [g], 3 + i % 4, seed=300 + i)
+        ids = seqs[0].numpy().astype(np.int32)
+        reqs.append(Request(ids, pv.numpy(), grid.numpy(), cap))
+        out, n = eng.generate(ids, np.array([len(ids)], np.int32), pv.numpy(), grid.numpy(), max_new_tokens=cap)
+        singles.append(out[0, :n[0]].tolist())
+    peak = []
+
+    class Watch:                                   # record the pool's low-water mark at every admission
+        def __init__(self, e): self._e = e
+        def __getattr__(self, k): return getattr(self._e, k)
+        def slots_prefill(self, *a):
+            self._e.slots_prefill(*a)
+            peak.append(self._e.kv_pool_info()[1])
+    got = ContinuousBatcher(Watch(small), chunk=8).run(reqs)
+    assert [g.tolist() for g in got] == singles
+    assert min(peak) >= 0 and min(peak) < 8 and small.kv_pool_info() == (16, 16)      # the pool really filled up, and drained
+    # a sequence that cannot fit is refused, the engine stays usable
+    ids = reqs[1].input_ids
+    text_only = ids[ids != cfg.image_token_id]
+    with pytest.raises(DotsEngineError, match="KV pool exhausted"):
+        small.slots_prefill([0, 1], np.concatenate([text_only, text_only]), [len(text_only), len(text_only)], [600, 600])
+    out, n = small.generate(ids, np.array([len(ids)], np.int32), reqs[1].pixel_values, reqs[1].grid_thw, max_new_tokens=20)
+    assert out[0, :20].tolist() == singles[1][:20]
+    small.close()
