@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
 // Why: at full MFMA rate a CU retires 4069 flop/clk; a BNxBM tile needs (BN+BM)/(BN*BM) bytes of
 // global->LDS traffic per flop, i.e. 64 B/clk for 128x128 — exactly the CU's L1/TA path (measured in
 // round 1: 128x128 and a 3-stage 256x128 variant both sit at 30-37 % MFMA utilisation with waves parked
-// 38 % of the time; profiles/r01_pmc_gemm_flash.txt).  256x256 needs 32 B/clk and halves LDS-read
+// 38 % of the time; profiles/r01_pmc_flash_gemm.json).  256x256 needs 32 B/clk and halves LDS-read
 // traffic per flop as well.  LDS: 2 stages x 64 KB (dynamic), LDS-DMA with the same source-side XOR
 // swizzle, one raw s_barrier per K-tile; the next tile's 8 DMA pieces per thread have a whole tile of
 // MFMAs (2048 cycles per SIMD) to land.  Used when N % 256 == 0.
@@ -286,12 +286,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(
 template <int E>
 static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R, void* C,
                                 int M, int N, int K, int lda, int ldc) {
-    static bool configured = false;          // one attribute call per instantiation (dynamic LDS > 64 KB)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_256_kernel<E>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
+    // dynamic LDS > 64 KB is opted into once per (instantiation, DEVICE): engines on several GPUs may live in one process
+    static uint32_t configured = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint32_t bit = 1u << (dev & 31);
+    if (!(__atomic_load_n(&configured, __ATOMIC_ACQUIRE) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_256_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         if (e != hipSuccess) return e;
-        configured = true;
+        __atomic_fetch_or(&configured, bit, __ATOMIC_RELEASE);
     }
     const int m_tiles = (M + BM2 - 1) / BM2, n_tiles = N / BN2;
     hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, R, C, M, N, K,

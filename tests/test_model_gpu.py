@@ -447,3 +447,17 @@ def test_paged_kv_pool_is_shared_and_recycled(setup):
     out, n = small.generate(ids, np.array([len(ids)], np.int32), reqs[1].pixel_values, reqs[1].grid_thw, max_new_tokens=20)
     assert out[0, :20].tolist() == singles[1][:20]
     small.close()
+
+
+def test_demo_hf_twin_runs_every_prompt_mode():
+    """SURVEY §8 a3 / BASELINE configs[0]: the reference's demo/demo_hf.py flow (every prompt mode over one image, reference
+    demo/demo_hf.py:10-71) through the same HF-shaped calls, on the engine (small-dims random-weight model, synthetic page)."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("demo_hf", Path(__file__).resolve().parent.parent / "demo" / "demo_hf.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.main(["--random-weights", "--tiny", "--max-new-tokens", "16", "--image", "no-such-file.jpg"])
+    from dots_ocr.utils import dict_promptmode_to_prompt
+    assert [r[0] for r in rows] == list(dict_promptmode_to_prompt) and all(1 <= r[2] <= 16 for r in rows)
+    assert all(r[1] > 19520 // 4 for r in rows)          # demo_image1.jpg's size: 1700 x 2250 -> 19 520 patches -> 4 880 vision tokens
