@@ -13,6 +13,9 @@ uint8 page pixels resident in HBM to strings on the host:
 Data-parallel: one process per GPU, a full replica each, pages sharded by page, the only collective being the final
 gather of token ids (RCCL).  --workload a4 / highres: weak scaling (B pages per GPU).  --workload mixed64: BASELINE
 configs[3], 64 mixed-size pages for the whole job, cost-sharded (LPT) over the ranks, continuous batching per rank: strong scaling.
+--workload svg: BASELINE configs[4] — one 588x560 chart page (420 vision tokens), prompt_image_to_svg with {width}/{height}
+filled (reference demo/demo_vllm_svg.py:28), 4096 new tokens, GREEDY (the reference samples this task at T = 0.9), fp8 (e4m3,
+per-output-channel scale) weights; B = 1.  --fp8 0/1 overrides the weight format of any workload.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the field contract).
 """
@@ -45,7 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="pages per GPU per step (sequence slots per GPU for mixed64)")
     ap.add_argument("--max-new-tokens", type=int, default=1024)
-    ap.add_argument("--workload", default="a4", choices=["a4", "highres", "tiny", "mixed64"])
+    ap.add_argument("--workload", default="a4", choices=["a4", "highres", "tiny", "mixed64", "svg"])
+    ap.add_argument("--fp8", type=int, default=None, help="1: e4m3 per-channel weights (DotsConfig.fp8_weights); default: on for --workload svg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -124,6 +128,13 @@ def mixed_pages(n_total, seed=2025):
 
 def main():
     a = parse()
+    if a.workload == "svg":                         # BASELINE configs[4]: one chart page, chart->SVG prompt, 4096 new tokens, fp8 weights
+        argv = " ".join(sys.argv[1:])
+        if "--batch" not in argv:
+            a.batch = 1
+        if "--max-new-tokens" not in argv:
+            a.max_new_tokens = 4096
+    fp8 = bool(a.fp8) if a.fp8 is not None else a.workload == "svg"
     if a.gpus > 1 and "RANK" not in os.environ:
         respawn_under_torchrun(a)
     import torch
@@ -146,6 +157,7 @@ def main():
     from dots_ocr_amd.image_utils import smart_resize
     from dots_ocr_amd.processing import IMG_PAD, DotsOcrProcessor
     from dots_ocr_amd.synthetic import A4_200DPI, HIGH_RES, synth_page
+    SVG_CHART = (588, 560)                          # demo/demo_image2.png-sized chart input
     from dots_ocr_amd.weights import random_state_dict
 
     cfg = DotsConfig.tiny(layers=4, v_layers=4) if a.workload == "tiny" else DotsConfig()
@@ -167,7 +179,7 @@ def main():
         my_pages = shards[rank]
         n_job_pages = len(sizes_all)
     else:
-        size = (420, 588) if a.workload == "tiny" else (A4_200DPI if a.workload == "a4" else HIGH_RES)
+        size = {"tiny": (420, 588), "a4": A4_200DPI, "highres": HIGH_RES, "svg": SVG_CHART}[a.workload]
         sizes_all = None
         my_pages = [rank * B + i for i in range(B)]
         n_job_pages = world * B
@@ -179,10 +191,14 @@ def main():
     slots = B
     max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
     eng = Engine(cfg, device=local, max_batch=slots, max_seq_len=max_seq, max_patches=max_patches,
-                 max_prefill_tokens=slots * max_prompt + 64)
+                 max_prefill_tokens=slots * max_prompt + 64, fp8_weights=fp8)
     eng.load_state_dict(sd)
     proc = DotsOcrProcessor(cfg, engine=eng)
-    prompt_text = json.loads((ROOT / "dots_ocr_amd" / "data" / "prompts.json").read_text())["prompt_layout_all_en"]
+    prompts_json = json.loads((ROOT / "dots_ocr_amd" / "data" / "prompts.json").read_text())
+    if a.workload == "svg":
+        prompt_text = prompts_json["prompt_image_to_svg"].replace("{width}", str(SVG_CHART[0])).replace("{height}", str(SVG_CHART[1]))
+    else:
+        prompt_text = prompts_json["prompt_layout_all_en"]
     messages = [{"role": "user", "content": [{"type": "image", "image": "page"}, {"type": "text", "text": prompt_text}]}]
 
     # inputs resident in HBM before the timed region: the uint8 pixels of every page; one fp32 patch buffer is reused
@@ -278,10 +294,12 @@ def main():
         pages_total = n_job_pages * K
         new_tok = sum(len(t) for _, t in gathered) * K
         res = {
-            "metric": f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)",
+            "metric": (f"pages/sec, dots.ocr 1.7B {'fp8 weights' if fp8 else 'bf16'}, chart->SVG page (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)"
+                       if a.workload == "svg" else
+                       f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)"),
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if mixed else "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic pages (PIL text lines) as uint8 pixels in HBM, seeded random weights at the checkpoint's dimensions",
+            "dtype": "fp8 e4m3 weights (per-output-channel fp32 scale) x bf16 activations, fp32 accumulate" if fp8 else "bf16", "data": "synthetic pages (PIL text lines) as uint8 pixels in HBM, seeded random weights at the checkpoint's dimensions",
             "output_tok_s": new_tok / dt, "rccl_ranks": n_ranks, "gathered_pages": len(gathered), "setup_s": setup_s,
         }
         if mixed:
@@ -320,6 +338,9 @@ def main():
                                       "algorithmic_bytes_per_decode_step": last["decode_bytes"] / max(1, last["decode_steps"]),
                                       "traffic": recorded("r02_decode_traffic.json", "traffic_bytes_per_decode_step"),
                                       "traffic_unit": "bytes per decode step (PMC, profiles/r02_decode_traffic.json)"}
+            if a.workload == "svg":                 # 4096 decode steps at B = 1 dominate this configuration: its roofline is the HBM one
+                res["roofline_vit_attn"] = res["roofline"]
+                res["roofline"] = {**res["roofline_decode"], "kernel": "one decode step (dec_qkv / decode_attn / combine / dec_proj / dec_gateup x 28 + dec_lmhead)"}
         if world == 1 and not a.no_cpu_baseline and a.workload == "a4":
             cores = min(os.cpu_count() or 1, 64)
             res["cpu_baseline"] = cpu_baseline(cfg, sd, cores, pages[0], prompts[0], a.max_new_tokens)

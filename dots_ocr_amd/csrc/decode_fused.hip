@@ -24,6 +24,10 @@
 // workgroups anywhere: every output element is complete inside one workgroup, the residual add happens in place.
 // The consumer of a residual-stream row recomputes its RMS statistic itself; numerics are identical to the standalone
 // norm kernel (bf16(bf16(x*rstd)*w)).
+// fp8 weights (quant.hip): every kernel is a template over the streamed fragment type WT — bf16x8 (16 B per lane and k-step) or
+// u32x2 (8 e4m3 bytes) — which is converted to the bf16 MFMA operand in registers (4 v_cvt_scalef32_pk_bf16_fp8, exact) when
+// its MFMA issues; the per-output-channel scale is one more small operand of step 1 and multiplies the reduced accumulator in
+// the epilogue.  Half the bytes per step, the same arithmetic as the bf16(q) x scale GEMMs of prefill.
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
@@ -123,21 +127,35 @@ DEVI void rows_norm_to_lds(const Rows<MAXR, NC>& R, int B, int dim, float eps, b
 // wave-uniform condition), so nothing has to be masked afterwards and a full slice costs no extra traffic.
 __device__ u32x4 g_zero_chunk[64];          // zero-initialised, one 1 KiB MFMA operand
 
-template <int G>
-DEVI void weights_issue(bf16x8 (&a)[G], const bf16x8* __restrict__ wp, int k0, int k1, int lane) {
-    const bf16x8* z = reinterpret_cast<const bf16x8*>(g_zero_chunk) + lane;
+template <int G, typename WT>
+DEVI void weights_issue(WT (&a)[G], const WT* __restrict__ wp, int k0, int k1, int lane) {
+    const WT* z = reinterpret_cast<const WT*>(g_zero_chunk) + lane;
 #pragma unroll
     for (int j = 0; j < G; ++j) a[j] = __builtin_nontemporal_load(k0 + j < k1 ? wp + (size_t)(k0 + j) * 64 : z);
 }
 
+// streamed fragment -> MFMA A operand
+DEVI bf16x8 as_a(bf16x8 v) { return v; }
+DEVI bf16x8 as_a(u32x2 v) {          // 8 e4m3 bytes (k ascending) -> 8 bf16, exact
+    const u32x4 o = {__builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[0], 1.0f, false)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[0], 1.0f, true)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[1], 1.0f, false)),
+                     __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v[1], 1.0f, true))};
+    return __builtin_bit_cast(bf16x8, o);
+}
+template <typename WT> struct is_fp8 { static constexpr bool value = false; };
+template <> struct is_fp8<u32x2> { static constexpr bool value = true; };
+// this lane's element of a (tile, k-step) chunk: full 16-row tile / 8-row half tile (decode_layout.h: bf16 [g][i], fp8 [i >> 3][g][i & 7])
+template <typename WT> DEVI int lane_slot(int g, int i) { return is_fp8<WT>::value ? fp8_lane_slot(g, i) : g * 16 + i; }
+
 // acc = W-tile[k0 .. k0+G) . X with X from the LDS image (xp = this lane's B-operand base, stride in bf16x8 units, KS rows)
-template <int G>
-DEVI f32x4 mfma_lds(const bf16x8 (&a)[G], const bf16x8* xp, int xstride, int k0, int KS) {
+template <int G, typename WT>
+DEVI f32x4 mfma_lds(const WT (&a)[G], const bf16x8* xp, int xstride, int k0, int KS) {
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], xp[(size_t)min(k0 + j, KS - 1) * xstride], acc0, 0, 0, 0);
-        if (j + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j + 1], xp[(size_t)min(k0 + j + 1, KS - 1) * xstride], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[j]), xp[(size_t)min(k0 + j, KS - 1) * xstride], acc0, 0, 0, 0);
+        if (j + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[j + 1]), xp[(size_t)min(k0 + j + 1, KS - 1) * xstride], acc1, 0, 0, 0);
     }
     return acc0 + acc1;
 }
@@ -158,9 +176,9 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restric
 // rows are two complete rotation pairs and the epilogue needs no exchange.  v heads keep the natural order.  Wave 15 owns the
 // epilogue; its operands (position, page id, bias, rotation angles) are fetched / computed while waves < B normalise the rows.
 // k-steps per wave = H / 32 / 16 <= NC (the same bound as the row chunks: H <= 512 NC).
-template <int NC>
+template <int NC, typename WT>
 __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
-                                                       const bf16_t* __restrict__ Wd, const bf16_t* __restrict__ bias,
+                                                       const WT* __restrict__ Wd, const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
                                                        const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
                                                        const int32_t* __restrict__ block_table, int max_pages,
                                                        bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out,
@@ -189,10 +207,15 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     const bf16_t* bp = bias ? bias + head * 128 : ln_w;           // always a valid address; masked below
     const uint32_t bia0 = *reinterpret_cast<const uint32_t*>(bp + f0), bia1 = *reinterpret_cast<const uint32_t*>(bp + f1);
     const float fr0 = inv_freq[f0 & 63], fr1 = inv_freq[(f0 + 1) & 63];
+    f32x2 sc0 = {1.f, 1.f}, sc1 = {1.f, 1.f};          // weight scales of rows (f0, f0 + 1), (f1, f1 + 1): the bias pattern
+    if constexpr (is_fp8<WT>::value) {
+        sc0 = *reinterpret_cast<const f32x2*>(wscale + head * 128 + f0);
+        sc1 = *reinterpret_cast<const f32x2*>(wscale + head * 128 + f1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- 2. weight slice: lane (g, i) reads row (i & 7) + 8 half of the chunk; rows of the other half are duplicates
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)tile * KS) * 64 + g * 16 + (m & 7) + 8 * half;
-    bf16x8 a[NC];
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
+    WT a[NC];
     weights_issue<NC>(a, wp, k0, k1, lane);
     __builtin_amdgcn_sched_barrier(0);
     const int page = block_table[mc * max_pages + (pos >> 6)];    // second (dependent) round trip, behind the weights
@@ -200,6 +223,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     // ---- 3. prologue math while the weights are in flight
     pin_rows<1, NC>(R);
     PIN(fr0); PIN(fr1); PIN(bia0); PIN(bia1);
+    if constexpr (is_fp8<WT>::value) { PIN(sc0); PIN(sc1); }
     TRACE(1);
     float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
     if (wv == 15 && rot) {      // precise sincosf (the fast path up to |x| < 2^17); runs beside the other waves' norm
@@ -225,6 +249,9 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     // bias of rows r = 0..3: rot (lo(bia0), lo(bia1), hi(bia0), hi(bia1)), else (lo(bia0), hi(bia0), lo(bia1), hi(bia1))
     const float b0 = bias ? lo_bf(bia0) : 0.f, b1 = bias ? (rot ? lo_bf(bia1) : hi_bf(bia0)) : 0.f;
     const float b2 = bias ? (rot ? hi_bf(bia0) : lo_bf(bia1)) : 0.f, b3 = bias ? hi_bf(bia1) : 0.f;
+    if constexpr (is_fp8<WT>::value) {
+        x[0] *= sc0[0]; x[1] *= rot ? sc1[0] : sc0[1]; x[2] *= rot ? sc0[1] : sc1[0]; x[3] *= sc1[1];
+    }
     const float y[4] = {bf2f(f2bf(x[0] + b0)), bf2f(f2bf(x[1] + b1)), bf2f(f2bf(x[2] + b2)), bf2f(f2bf(x[3] + b3))};   // the qkv output is a bf16 tensor
     if (rot) {
         // pairs (y0, y1) = features (d, d + 64) and (y2, y3) = (d + 1, d + 65)
@@ -253,8 +280,11 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
 // grid N/8 workgroups (one 8-row half tile over the FULL K) x 16 waves (K-slices); X arrives as the X image from the
 // previous kernel (L2 / Infinity Cache): its loads and the residual go first.  A slice longer than G k-steps runs in rounds
 // of G with the next round's loads issued before this round's MFMAs (down_proj at K = 8960: 17-18 k-steps per wave, G = 6).
-template <int G>
-__global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wd,
+#ifndef PROJ_G_FP8
+#define PROJ_G_FP8 6
+#endif
+template <int G, typename WT>
+__global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
                                                         bf16_t* __restrict__ h, int B, int N, int K, int XR) {
     __shared__ f32x4 red[16 * 64];
     const int lane = threadIdx.x & 63, wv = wave_id();
@@ -263,13 +293,16 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
     const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);
     const int m = lane & 15, g = lane >> 4;
     const bool epi = wv == 15 && m < B && g < 2;
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)tile * KS) * 64 + g * 16 + (m & 7) + 8 * half;
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(X) + g * XR + (m & (XR - 1));
     const int xstride = 4 * XR;
     bf16_t* hp = h + (size_t)min(m, B - 1) * N + tile * 16 + 8 * half + 4 * (g & 1);
     TRACE(0);
     const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
-    bf16x8 a[G], b[G];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + tile * 16 + 8 * half + 4 * (g & 1));
+    WT a[G];
+    bf16x8 b[G];
 #pragma unroll
     for (int jj = 0; jj < G; ++jj) b[jj] = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
     __builtin_amdgcn_sched_barrier(0);
@@ -278,32 +311,35 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     int ks = k0;
     for (; ks + G < k1; ks += G) {                        // all rounds but the last
-        bf16x8 an[G], bn[G];
+        WT an[G];
+        bf16x8 bn[G];
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) bn[jj] = xp[(size_t)min(ks + G + jj, KS - 1) * xstride];
         weights_issue<G>(an, wp, ks + G, k1, lane);
 #pragma unroll
         for (int jj = 0; jj < G; jj += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], b[jj], acc0, 0, 0, 0);
-            if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], b[jj + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj]), b[jj], acc0, 0, 0, 0);
+            if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj + 1]), b[jj + 1], acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) { a[jj] = an[jj]; b[jj] = bn[jj]; }
     }
 #pragma unroll
     for (int jj = 0; jj < G; jj += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], b[jj], acc0, 0, 0, 0);
-        if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], b[jj + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj]), b[jj], acc0, 0, 0, 0);
+        if (jj + 1 < G) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj + 1]), b[jj + 1], acc1, 0, 0, 0);
     }
     TRACE(1);
     red[wv * 64 + lane] = acc0 + acc1;
     PIN(res);
+    if constexpr (is_fp8<WT>::value) PIN(sc);
     __syncthreads();
     TRACE(2);
     if (!epi) return;
     f32x4 s = {0, 0, 0, 0};
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) s += red[sl * 64 + lane];
+    if constexpr (is_fp8<WT>::value) s *= sc;
     const u32x2 o = {pack_bf2(lo_bf(res[0]) + s[0], hi_bf(res[0]) + s[1]), pack_bf2(lo_bf(res[1]) + s[2], hi_bf(res[1]) + s[3])};
     *reinterpret_cast<u32x2*>(hp) = o;
     TRACE(3);
@@ -320,9 +356,9 @@ constexpr int GU_WAVES = 4;      // 12 (single round) was measured slower: 12 wa
 constexpr int GU_EARLY = GU_EARLY_N;      // k-steps requested before the norm prologue; the rest right after it, when the row registers
                                  // are free: all I/16 workgroups are resident only at 3 waves per SIMD, i.e. <= 168 VGPRs
 
-template <int MAXR, int NC>
+template <int MAXR, int NC, typename WT>
 __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
-                                                                   const bf16_t* __restrict__ Wd, bf16_t* __restrict__ act,
+                                                                   const WT* __restrict__ Wd, const float* __restrict__ wscale, bf16_t* __restrict__ act,
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
@@ -333,14 +369,20 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     const int k0 = wv * KS / GU_WAVES, k1 = (wv + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
     const int xstride = 4 * XR;
-    const bf16x8* wg = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + a) * KS) * 64 + lane;
-    const bf16x8* wu = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)(G * 4 + 2 + a) * KS) * 64 + lane;
+    const int ls = lane_slot<WT>(lane >> 4, lane & 15);
+    const WT* wg = Wd + ((size_t)(G * 4 + a) * KS) * 64 + ls;
+    const WT* wu = Wd + ((size_t)(G * 4 + 2 + a) * KS) * 64 + ls;
     TRACE(0);
     Rows<MAXR, NC> R;
     rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, GU_WAVES, lane);
+    f32x4 scg = {1.f, 1.f, 1.f, 1.f}, scu = {1.f, 1.f, 1.f, 1.f};       // packed-W13 rows (G*4 + a)*16 + 4g + r (gate), + 32 (up)
+    if constexpr (is_fp8<WT>::value) {
+        scg = *reinterpret_cast<const f32x4*>(wscale + (G * 4 + a) * 16 + 4 * (lane >> 4));
+        scu = *reinterpret_cast<const f32x4*>(wscale + (G * 4 + 2 + a) * 16 + 4 * (lane >> 4));
+    }
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 a_[GU_G], u_[GU_G];
-    const bf16x8* zc = reinterpret_cast<const bf16x8*>(g_zero_chunk) + lane;
+    WT a_[GU_G], u_[GU_G];
+    const WT* zc = reinterpret_cast<const WT*>(g_zero_chunk) + lane;
 #pragma unroll
     for (int jj = 0; jj < GU_EARLY; ++jj) {
         a_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wg + (size_t)(k0 + jj) * 64 : zc);
@@ -348,6 +390,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     }
     __builtin_amdgcn_sched_barrier(0);
     pin_rows<MAXR, NC>(R);
+    if constexpr (is_fp8<WT>::value) { PIN(scg); PIN(scu); }
     TRACE(1);
     rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, GU_WAVES, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -364,8 +407,8 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
 #pragma unroll
     for (int jj = 0; jj < GU_G; ++jj) {
         const bf16x8 b = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
-        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[jj], b, ag, 0, 0, 0);
-        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[jj], b, au, 0, 0, 0);
+        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a_[jj]), b, ag, 0, 0, 0);
+        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(u_[jj]), b, au, 0, 0, 0);
     }
     TRACE(4);
     red[(wv * 2) * 64 + lane] = ag;
@@ -377,6 +420,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     f32x4 gs = ag, us = au;
 #pragma unroll
     for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[(ww * 2) * 64 + lane]; us += red[(ww * 2 + 1) * 64 + lane]; }
+    if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
@@ -388,25 +432,33 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
 // logits[m][n] = rmsnorm(h[m]) . lm_head[n]   (fp32, never rounded).  grid ceil(V/256) workgroups x 16 waves, wave = one
 // 16-row vocabulary tile over the full K in rounds of LM_G k-steps (the next round's loads are issued before this round's
 // MFMAs).  16 tiles per workgroup share one norm prologue.
-constexpr int LM_G = 8;
+#ifndef LM_G_FP8
+#define LM_G_FP8 8
+#endif
+template <typename WT> struct LmG { static constexpr int value = 8; };
+template <> struct LmG<u32x2> { static constexpr int value = LM_G_FP8; };
 
-template <int NC>
+template <int NC, typename WT>
 __global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
-                                                          const bf16_t* __restrict__ Wd, float* __restrict__ logits,
+                                                          const WT* __restrict__ Wd, const float* __restrict__ wscale, float* __restrict__ logits,
                                                           int B, int H, int V, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int n_tile = min((int)blockIdx.x * 16 + wv, V / 16 - 1);     // tail waves recompute the last tile (same values)
     const int KS = H / 32;                                             // a multiple of LM_G (launcher)
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(Wd) + ((size_t)n_tile * KS) * 64 + lane;
+    constexpr int LM_G = LmG<WT>::value;
+    const WT* wp = Wd + ((size_t)n_tile * KS) * 64 + lane_slot<WT>(lane >> 4, lane & 15);
     Rows<1, NC> R;
     rows_issue<1, NC>(R, h, ln_w, B, H, wv, 16, lane);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + n_tile * 16 + 4 * (lane >> 4));
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 a[LM_G];
+    WT a[LM_G];
     weights_issue<LM_G>(a, wp, 0, KS, lane);
     __builtin_amdgcn_sched_barrier(0);
     pin_rows<1, NC>(R);
+    if constexpr (is_fp8<WT>::value) PIN(sc);
     rows_norm_to_lds<1, NC>(R, B, H, eps, xs, XR, wv, 16, lane);
     __syncthreads();
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
@@ -414,22 +466,23 @@ __global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restri
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     int ks = 0;
     for (; ks + LM_G < KS; ks += LM_G) {                 // all rounds but the last: next round's loads first
-        bf16x8 an[LM_G];
+        WT an[LM_G];
         weights_issue<LM_G>(an, wp, ks + LM_G, KS, lane);
 #pragma unroll
         for (int jj = 0; jj < LM_G; jj += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj]), xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj + 1]), xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < LM_G; ++jj) a[jj] = an[jj];
     }
 #pragma unroll
     for (int jj = 0; jj < LM_G; jj += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj], xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jj + 1], xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj]), xp[(size_t)(ks + jj) * xstride], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj + 1]), xp[(size_t)(ks + jj + 1) * xstride], acc1, 0, 0, 0);
     }
-    const f32x4 acc = acc0 + acc1;
+    f32x4 acc = acc0 + acc1;
+    if constexpr (is_fp8<WT>::value) acc *= sc;
     const int m = lane & 15, g = lane >> 4;
     if (m < B) *reinterpret_cast<f32x4*>(logits + (size_t)m * V + n_tile * 16 + 4 * g) = acc;
 }
@@ -461,57 +514,87 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, const bf16_t* bias,
+// Wd / wscale of the launchers: wscale == nullptr -> Wd is the bf16 fragment image (launch_pack_frag*), else Wd is the e4m3
+// fragment image (launch_pack_frag_fp8) and wscale its per-row fp32 scales.
+hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
-    static uint32_t attr = 0;
+    static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
-    hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX>, lds_max, &attr);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_qkv_kernel<NC_MAX>, dim3((Hq + 2 * Hkv) * 16), dim3(1024), lds, s, h, ln_w, Wd, bias, inv_freq, ctx_len,
-                       block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
+    const dim3 grid((Hq + 2 * Hkv) * 16);
+    if (wscale) {
+        hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, u32x2>, lds_max, &attr[1]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dec_qkv_kernel<NC_MAX, u32x2>), grid, dim3(1024), lds, s, h, ln_w, (const u32x2*)Wd, wscale, bias, inv_freq, ctx_len,
+                           block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
+    } else {
+        hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, bf16x8>, lds_max, &attr[0]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((dec_qkv_kernel<NC_MAX, bf16x8>), grid, dim3(1024), lds, s, h, ln_w, (const bf16x8*)Wd, wscale, bias, inv_freq, ctx_len,
+                           block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const bf16_t* Wd, bf16_t* h, int B, int N, int K) {
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > 16) return hipErrorInvalidValue;
     const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
     const dim3 grid(N / 8);
-#define PROJ_CASE(G) hipLaunchKernelGGL(dec_proj_kernel<G>, grid, dim3(1024), 0, s, X, Wd, h, B, N, K, XR)
+#define PROJ_CASE(G)                                                                                                                   \
+    do {                                                                                                                               \
+        if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);  \
+        else hipLaunchKernelGGL((dec_proj_kernel<G, bf16x8>), grid, dim3(1024), 0, s, X, (const bf16x8*)Wd, wscale, h, B, N, K, XR);       \
+    } while (0)
     if (need <= 1) PROJ_CASE(1);
     else if (need <= 2) PROJ_CASE(2);
     else if (need <= 3) PROJ_CASE(3);
     else if (need <= 4) PROJ_CASE(4);
+    else if (wscale) hipLaunchKernelGGL((dec_proj_kernel<PROJ_G_FP8, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);
     else PROJ_CASE(6);
 #undef PROJ_CASE
     return hipGetLastError();
 }
 
-hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* W13d, bf16_t* act,
-                             int B, int H, int I, float eps) {
-    if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > 16) return hipErrorInvalidValue;
+template <typename WT>
+static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const WT* W13d, const float* wscale, bf16_t* act,
+                                int B, int H, int I, float eps) {
     static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
     const size_t lds_max = (size_t)16 * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
     const int v = B <= 8 ? 0 : 1;
-    auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX> : dec_gateup_kernel<4, NC_MAX>;
+    auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT> : dec_gateup_kernel<4, NC_MAX, WT>;
     hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, act, B, H, I, eps, XR);
+    hipLaunchKernelGGL(kern, dim3(I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
     return hipGetLastError();
 }
 
-hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, float* logits,
-                             int B, int H, int V, float eps) {
-    if (V % 16 || H % (32 * LM_G) || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
+                             int B, int H, int I, float eps) {
+    if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > 16) return hipErrorInvalidValue;
+    return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps)
+                  : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps);
+}
+
+template <typename WT>
+static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const WT* Wd, const float* wscale, float* logits,
+                                int B, int H, int V, float eps) {
+    if (H % (32 * LmG<WT>::value)) return hipErrorInvalidValue;
     static uint32_t attr = 0;
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2;
-    hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX>, (size_t)16 * H * 2, &attr);
+    hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX, WT>, (size_t)16 * H * 2, &attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dec_lmhead_kernel<NC_MAX>, dim3((V / 16 + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, logits, B, H, V, eps, XR);
+    hipLaunchKernelGGL((dec_lmhead_kernel<NC_MAX, WT>), dim3((V / 16 + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, wscale, logits, B, H, V, eps, XR);
     return hipGetLastError();
+}
+
+hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
+                             int B, int H, int V, float eps) {
+    if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+    return wscale ? lmhead_launch(s, h, ln_w, (const u32x2*)Wd, wscale, logits, B, H, V, eps)
+                  : lmhead_launch(s, h, ln_w, (const bf16x8*)Wd, wscale, logits, B, H, V, eps);
 }

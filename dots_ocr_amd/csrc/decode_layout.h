@@ -12,6 +12,9 @@ constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
 //   inputs   X[(k/8)*XR + m][8]  <->  X[m][8*(k/8) .. +7],   XR = 8 (B <= 8) or 16 rows
 //            lane (g, m) of k-step ks reads slot (4*ks + g)*XR + (m & (XR-1)): with XR = 8 lanes m and m+8 read the same 16 B,
 //            so an 8-row batch costs half the L2 traffic and half the LDS of the 16-row image.
+// fp8 weights (quant.hip): the chunk of a (tile, k-step) is 512 B, lane (g, i)'s 8 bytes sit at 8-byte slot [i >> 3][g][i & 7]: each 8-row half
+// of the tile is 256 contiguous bytes (two whole lines).
+DEVI int fp8_lane_slot(int g, int i) { return ((i >> 3) * 4 + g) * 8 + (i & 7); }
 DEVI int xr_of(int B) { return B <= 8 ? 8 : 16; }
 DEVI size_t xfrag_off(int m, int k, int XR) { return ((size_t)(k >> 3) * XR + m) * 8 + (k & 7); }
 

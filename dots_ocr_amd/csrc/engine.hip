@@ -32,10 +32,16 @@ struct Tensor {
     int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 
-struct VLayer { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *w13, *b13, *w2, *b2; };
+// *_s: per-output-channel fp32 scales of the fp8 configuration (cfg.fp8_weights; quant.hip), nullptr in bf16 mode.  In fp8 mode the
+// row-major matrices hold bf16(q) (exact e4m3 values) and the decode copies (*_wd) hold the e4m3 bytes in fragment order.
+struct VLayer {
+    bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *w13, *b13, *w2, *b2;
+    float *qkv_s, *proj_s, *w13_s, *w2_s;
+};
 struct LLayer {
     bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *w13, *down_w;          // row-major [N][K]: prefill GEMMs
-    bf16_t *qkv_wd, *o_wd, *w13_wd, *down_wd;                        // MFMA fragment order: decode skinny GEMMs
+    void *qkv_wd, *o_wd, *w13_wd, *down_wd;                          // MFMA fragment order: decode skinny GEMMs
+    float *qkv_s, *o_s, *w13_s, *down_s;
 };
 
 __global__ void pack_w13_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up, bf16_t* __restrict__ out, int I, int K) {
@@ -101,7 +107,9 @@ struct DotsEngine {
     int patch_k = 0, patch_kpad = 0;
     std::vector<VLayer> vl;
     bf16_t *v_post_norm = nullptr, *m_ln_w = nullptr, *m_ln_b = nullptr, *m0_w = nullptr, *m0_b = nullptr, *m2_w = nullptr, *m2_b = nullptr;
-    bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr, *lm_head_d = nullptr;
+    bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
+    void* lm_head_d = nullptr;
+    float *m0_s = nullptr, *m2_s = nullptr, *lm_head_s = nullptr;
     std::vector<LLayer> ll;
     float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
 
@@ -245,6 +253,33 @@ void drop(DotsEngine* e, const std::string& name) {
 
 #define RET(x) do { int r_ = (x); if (r_ != DOTS_OK) return r_; } while (0)
 
+// fp8 mode: W <- bf16(q) in place + a fresh scale array; bf16 mode: *scale = nullptr
+int quantize(DotsEngine* e, bf16_t* W, float** scale, int64_t N, int K) {
+    *scale = nullptr;
+    if (!e->cfg.fp8_weights) return DOTS_OK;
+    CK(e->alloc(scale, (size_t)N));
+    CK(launch_quant_rows_fp8(e->stream, W, *scale, N, K));
+    return DOTS_OK;
+}
+
+// decode copy of a (quantised) row-major matrix: bf16 fragments, or e4m3 fragments in fp8 mode
+int decode_copy(DotsEngine* e, const bf16_t* W, void** out, int64_t rows, int K, int rot_rows) {
+    const size_t elems = (size_t)((rows + 15) / 16 * 16) * K;
+    if (e->cfg.fp8_weights) {
+        uint8_t* d = nullptr;
+        CK(e->alloc(&d, elems));
+        CK(launch_pack_frag_fp8(e->stream, W, d, rows, K, rot_rows));
+        *out = d;
+    } else {
+        bf16_t* d = nullptr;
+        CK(e->alloc(&d, elems));
+        if (rot_rows) CK(launch_pack_frag_qkv(e->stream, W, d, e->cfg.num_heads, e->cfg.num_kv_heads, K));
+        else CK(launch_pack_frag(e->stream, W, d, rows, K));
+        *out = d;
+    }
+    return DOTS_OK;
+}
+
 int finalize_weights(DotsEngine* e) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
@@ -288,6 +323,10 @@ int finalize_weights(DotsEngine* e) {
             CK(e->alloc(&L.b13, (size_t)2 * Iv));
             hipLaunchKernelGGL(pack_b13_kernel, dim3((2 * Iv + 255) / 256), dim3(256), 0, s, b1, b3, L.b13, Iv);
         }
+        RET(quantize(e, L.qkv_w, &L.qkv_s, 3 * E, E));
+        RET(quantize(e, L.proj_w, &L.proj_s, E, E));
+        RET(quantize(e, L.w13, &L.w13_s, 2 * Iv, E));          // packed row order: the scale index the SwiGLU epilogue uses
+        RET(quantize(e, L.w2, &L.w2_s, E, Iv));
         CK(hipStreamSynchronize(s));
         drop(e, p + "mlp.fc1.weight");
         drop(e, p + "mlp.fc3.weight");
@@ -300,6 +339,8 @@ int finalize_weights(DotsEngine* e) {
     RET(need(e, "vision_tower.merger.mlp.0.bias", {Mg}, &e->m0_b));
     RET(need(e, "vision_tower.merger.mlp.2.weight", {c.hidden_size, Mg}, &e->m2_w));
     RET(need(e, "vision_tower.merger.mlp.2.bias", {c.hidden_size}, &e->m2_b));
+    RET(quantize(e, e->m0_w, &e->m0_s, Mg, Mg));
+    RET(quantize(e, e->m2_w, &e->m2_s, c.hidden_size, Mg));
 
     // ---- language model
     const int H = c.hidden_size, I = c.intermediate_size, Nq = c.num_heads * 128, Nkv = c.num_kv_heads * 128;
@@ -307,8 +348,18 @@ int finalize_weights(DotsEngine* e) {
     RET(need(e, "model.norm.weight", {H}, &e->final_norm));
     if (find(e, "lm_head.weight")) RET(need(e, "lm_head.weight", {c.vocab_size, H}, &e->lm_head));
     else e->lm_head = e->embed;                      // tie_word_embeddings
-    CK(e->alloc(&e->lm_head_d, (size_t)c.vocab_size * H));
-    CK(launch_pack_frag(s, e->lm_head, e->lm_head_d, c.vocab_size, H));
+    if (c.fp8_weights) {                             // the embedding table stays bf16: quantise a copy of the (possibly tied) head
+        bf16_t* tmp = nullptr;
+        CK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)c.vocab_size * H * 2));
+        hipError_t r = hipMemcpyAsync(tmp, e->lm_head, (size_t)c.vocab_size * H * 2, hipMemcpyDeviceToDevice, s);
+        int rc = r == hipSuccess ? quantize(e, tmp, &e->lm_head_s, c.vocab_size, H) : DOTS_E_HIP;
+        if (rc == DOTS_OK) rc = decode_copy(e, tmp, &e->lm_head_d, c.vocab_size, H, 0);
+        hipStreamSynchronize(s);
+        hipFree(tmp);
+        if (rc != DOTS_OK) return r == hipSuccess ? rc : e->fail(DOTS_E_HIP, "lm_head copy failed: %s", hipGetErrorString(r));
+    } else {
+        RET(decode_copy(e, e->lm_head, &e->lm_head_d, c.vocab_size, H, 0));
+    }
     e->ll.resize(c.num_layers);
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
@@ -339,15 +390,15 @@ int finalize_weights(DotsEngine* e) {
         }
         CK(e->alloc(&L.w13, (size_t)2 * I * H));
         CK(launch_pack_w13(s, gw, uw, L.w13, I, H));
-        // decode copies in MFMA fragment order (+3.1 GB of 288 GB: every decode weight load is a contiguous 1 KiB)
-        CK(e->alloc(&L.qkv_wd, (size_t)(Nq + 2 * Nkv) * H));
-        CK(e->alloc(&L.o_wd, (size_t)H * Nq));
-        CK(e->alloc(&L.w13_wd, (size_t)2 * I * H));
-        CK(e->alloc(&L.down_wd, (size_t)H * I));
-        CK(launch_pack_frag_qkv(s, L.qkv_w, L.qkv_wd, c.num_heads, c.num_kv_heads, H));      // q / k rows permuted: whole RoPE pairs per tile
-        CK(launch_pack_frag(s, L.o_w, L.o_wd, H, Nq));
-        CK(launch_pack_frag(s, L.w13, L.w13_wd, 2 * I, H));
-        CK(launch_pack_frag(s, L.down_w, L.down_wd, H, I));
+        RET(quantize(e, L.qkv_w, &L.qkv_s, Nq + 2 * Nkv, H));
+        RET(quantize(e, L.o_w, &L.o_s, H, Nq));
+        RET(quantize(e, L.w13, &L.w13_s, 2 * I, H));
+        RET(quantize(e, L.down_w, &L.down_s, H, I));
+        // decode copies in MFMA fragment order (+3.1 GB of 288 GB, half of that in fp8 mode: every decode weight load is one contiguous chunk)
+        RET(decode_copy(e, L.qkv_w, &L.qkv_wd, Nq + 2 * Nkv, H, Nq + Nkv));                   // q / k rows permuted: whole RoPE pairs per tile
+        RET(decode_copy(e, L.o_w, &L.o_wd, H, Nq, 0));
+        RET(decode_copy(e, L.w13, &L.w13_wd, 2 * I, H, 0));
+        RET(decode_copy(e, L.down_w, &L.down_wd, H, I, 0));
         CK(hipStreamSynchronize(s));
         for (const char* n : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                               "mlp.gate_proj.weight", "mlp.up_proj.weight"})
@@ -548,16 +599,16 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = e->vl[i];
         CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
-        CK(launch_gemm(s, e->v_xn, L.qkv_w, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, E, 3 * E, EPI_NONE));
+        CK(launch_gemm(s, e->v_xn, L.qkv_w, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, E, 3 * E, EPI_NONE, L.qkv_s));
         CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
         CK(attn_event(e, 2 * i));
         CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale));
         CK(attn_event(e, 2 * i + 1));
         e->attn_pairs = i + 1;
-        CK(launch_gemm(s, e->v_att, L.proj_w, L.proj_b, e->v_x, e->v_x, N, E, E, E, E, EPI_RESIDUAL));
+        CK(launch_gemm(s, e->v_att, L.proj_w, L.proj_b, e->v_x, e->v_x, N, E, E, E, E, EPI_RESIDUAL, L.proj_s));
         CK(launch_rmsnorm(s, e->v_x, L.norm2, e->v_xn, N, E, c.v_rms_eps));
-        CK(launch_gemm(s, e->v_xn, L.w13, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, E, c.v_intermediate, EPI_SWIGLU));
-        CK(launch_gemm(s, e->v_act, L.w2, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, c.v_intermediate, E, EPI_RESIDUAL));
+        CK(launch_gemm(s, e->v_xn, L.w13, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, E, c.v_intermediate, EPI_SWIGLU, L.w13_s));
+        CK(launch_gemm(s, e->v_act, L.w2, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, c.v_intermediate, E, EPI_RESIDUAL, L.w2_s));
         if (e->dbg_hidden && (size_t)(i + 1) * N * E <= e->dbg_cap) {
             CK(hipMemcpyAsync(e->dbg_hidden + (size_t)i * N * E, e->v_x, (size_t)N * E * 2, hipMemcpyDeviceToDevice, s));
             e->dbg_vit_rows = N;
@@ -571,8 +622,8 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     CK(launch_layernorm(s, xin, e->m_ln_w, e->m_ln_b, e->v_att, N, E, c.v_ln_eps));
     const int g = m * m, Mg = E * g;
     const int64_t R = N / g;
-    CK(launch_gemm(s, e->v_att, e->m0_w, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, Mg, EPI_GELU));
-    CK(launch_gemm(s, e->v_mh, e->m2_w, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, Mg, c.hidden_size, EPI_NONE));
+    CK(launch_gemm(s, e->v_att, e->m0_w, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, Mg, EPI_GELU, e->m0_s));
+    CK(launch_gemm(s, e->v_mh, e->m2_w, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, Mg, c.hidden_size, EPI_NONE, e->m2_s));
     CK(hipEventRecord(e->ev[1], s));
     e->vis_rows = R;
     if (out_dev) CK(hipMemcpyAsync(out_dev, e->vis, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
@@ -705,14 +756,14 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         const LLayer& Lw = e->ll[i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_rmsnorm(s, e->p_x, Lw.ln1, e->p_xn, T, H, c.rms_norm_eps));
-        CK(launch_gemm(s, e->p_xn, Lw.qkv_w, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, H, NQKV, EPI_NONE));
+        CK(launch_gemm(s, e->p_xn, Lw.qkv_w, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, H, NQKV, EPI_NONE, Lw.qkv_s));
         CK(launch_qkv_rope_split(s, e->p_qkv, e->p_cs, e->p_tiles, n_tiles, e->p_q, e->p_k, e->p_vt, T, Tpad, Hq, Hkv));
         CK(launch_kv_to_pages(s, e->p_k, e->p_qkv, e->p_tiles, n_tiles, e->block_table, e->max_pages, pool_l, T, Hq, Hkv));
         CK(launch_flash_attn(s, e->p_q, e->p_k, e->p_vt, e->p_att, e->p_qblocks, (int)e->hp_qblocks.size(), T, Tpad, Hq, Hkv, 1, scale));
-        CK(launch_gemm(s, e->p_att, Lw.o_w, nullptr, e->p_x, e->p_x, T, H, Nq, Nq, H, EPI_RESIDUAL));
+        CK(launch_gemm(s, e->p_att, Lw.o_w, nullptr, e->p_x, e->p_x, T, H, Nq, Nq, H, EPI_RESIDUAL, Lw.o_s));
         CK(launch_rmsnorm(s, e->p_x, Lw.ln2, e->p_xn, T, H, c.rms_norm_eps));
-        CK(launch_gemm(s, e->p_xn, Lw.w13, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, H, c.intermediate_size, EPI_SWIGLU));
-        CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL));
+        CK(launch_gemm(s, e->p_xn, Lw.w13, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, H, c.intermediate_size, EPI_SWIGLU, Lw.w13_s));
+        CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL, Lw.down_s));
         const size_t voff = (size_t)c.v_layers * e->dbg_vit_rows * c.v_embed_dim;       // LM layers are stored behind the ViT blocks
         if (e->dbg_hidden && voff + (size_t)(i + 1) * T * H <= e->dbg_cap) {
             CK(hipMemcpyAsync(e->dbg_hidden + voff + (size_t)i * T * H, e->p_x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
@@ -721,7 +772,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     }
     // last position of every sequence -> final norm -> lm_head -> first token
     CK(launch_gather_rows(s, e->p_x, e->p_last, slots ? e->p_dst : nullptr, e->d_h, B, H));
-    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->d_logits, rows, H, c.vocab_size, c.rms_norm_eps));
+    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, rows, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = rows;
     e->sel_now = e->d_sel_new;
     RET(select_tokens(e, 0));
@@ -759,15 +810,15 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
     for (int i = 0; i < c.num_layers; ++i) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
-        CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
+        CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
                           Hkv, c.rms_norm_eps));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
-        CK(launch_dec_proj(s, e->d_att, L.o_wd, e->d_h, B, H, Nq));
-        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, e->d_act, B, H, I, c.rms_norm_eps));
-        CK(launch_dec_proj(s, e->d_act, L.down_wd, e->d_h, B, H, I));
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq));
+        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps));
+        CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I));
     }
-    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
+    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = B;
     e->sel_now = e->d_sel;
     RET(select_tokens(e, 1));
@@ -795,8 +846,12 @@ int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_
 
 double decode_step_bytes(const DotsConfig& c) {
     const double H = c.hidden_size, Nq = c.num_heads * 128.0, Nkv = c.num_kv_heads * 128.0, I = c.intermediate_size;
-    const double per_layer = H * (Nq + 2 * Nkv) + (c.attention_bias ? Nq + 2 * Nkv : 0) + Nq * H + 3 * H * I + 2 * H;
-    return 2.0 * (c.num_layers * per_layer + H + (double)c.vocab_size * H);
+    // every weight byte once per step.  bf16: 2 B per weight; fp8 mode: 1 B per linear weight + 4 B per output channel
+    // (scale), norms and biases stay bf16
+    const double lin = H * (Nq + 2 * Nkv) + Nq * H + 3 * H * I, chans = (Nq + 2 * Nkv) + H + 2 * I + H;
+    const double small = 2.0 * ((c.attention_bias ? Nq + 2 * Nkv : 0) + 2 * H);
+    if (c.fp8_weights) return c.num_layers * (lin + 4.0 * chans + small) + 2.0 * H + (double)c.vocab_size * (H + 4.0);
+    return c.num_layers * (2.0 * lin + small) + 2.0 * H + 2.0 * (double)c.vocab_size * H;
 }
 
 }  // namespace
@@ -818,6 +873,30 @@ struct Scratch {
         for (void* p : ptrs) e->release(p);
     }
 };
+
+// Decode operand of a single-kernel entry point from a ROW-MAJOR bf16 weight: bf16 fragments (fp8 == 0), or a quantised copy packed
+// as e4m3 fragments + its scales — the same kernels dots_finalize_weights runs.
+int op_weight(DotsEngine* e, Scratch& sc, const bf16_t* w, int64_t rows, int K, int Hq, int Hkv, bool qkv, int fp8, void** wd, float** scale) {
+    *scale = nullptr;
+    if (fp8) {
+        bf16_t* q = nullptr;
+        uint8_t* d = nullptr;
+        CK(sc.get(&q, (size_t)rows * K));
+        CK(sc.get(scale, (size_t)rows));
+        CK(sc.get(&d, (size_t)((rows + 15) / 16 * 16) * K));
+        CK(hipMemcpyAsync(q, w, (size_t)rows * K * 2, hipMemcpyDeviceToDevice, e->stream));
+        CK(launch_quant_rows_fp8(e->stream, q, *scale, rows, K));
+        CK(launch_pack_frag_fp8(e->stream, q, d, rows, K, qkv ? (Hq + Hkv) * 128 : 0));
+        *wd = d;
+    } else {
+        bf16_t* d = nullptr;
+        CK(sc.get(&d, (size_t)((rows + 15) / 16 * 16) * K));
+        if (qkv) CK(launch_pack_frag_qkv(e->stream, w, d, Hq, Hkv, K));
+        else CK(launch_pack_frag(e->stream, w, d, rows, K));
+        *wd = d;
+    }
+    return DOTS_OK;
+}
 }  // namespace
 
 // ===================================================================================== C ABI
@@ -1294,11 +1373,19 @@ int dots_op_layernorm(DotsEngine* e, const void* x, const void* w, const void* b
     return DOTS_OK;
 }
 int dots_op_gemm(DotsEngine* e, const void* A, const void* W, const void* bias, const void* residual, void* C,
-                 int64_t M, int N, int K, int epilogue) {
+                 int64_t M, int N, int K, int epilogue, const float* colscale) {
     if (!e) return DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     const int ldc = epilogue == EPI_SWIGLU ? N / 2 : N;
-    CK(launch_gemm(e->stream, (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)residual, C, M, N, K, K, ldc, epilogue));
+    CK(launch_gemm(e->stream, (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)residual, C, M, N, K, K, ldc, epilogue, colscale));
+    return DOTS_OK;
+}
+
+int dots_op_quant_fp8(DotsEngine* e, void* w_inout, float* scale_out, int64_t N, int K) {
+    if (!e || !w_inout || !scale_out) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    CK(launch_quant_rows_fp8(e->stream, (bf16_t*)w_inout, scale_out, N, K));
+    CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
 
@@ -1370,19 +1457,18 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, voi
 
 int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* wqkv, const void* bias, const int32_t* ctx_len_dev,
                     const int32_t* block_table_dev, int max_pages, void* pool_layer, void* q_out, int B, int H, int Hq, int Hkv, float eps,
-                    float rope_theta) {
+                    float rope_theta, int fp8) {
     if (!e || !h || !ln_w || !wqkv || !ctx_len_dev || !block_table_dev || !pool_layer || !q_out) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
-    bf16_t* wd = nullptr;
-    float* freq = nullptr;
-    CK(sc.get(&wd, (size_t)(Hq + 2 * Hkv) * 128 * H));
+    void* wd = nullptr;
+    float *freq = nullptr, *wscale = nullptr;
     CK(sc.get(&freq, 64));
     float f[64];
     for (int i = 0; i < 64; ++i) f[i] = 1.0f / powf(rope_theta, (float)(2 * i) / 128.0f);
     CK(hipMemcpyAsync(freq, f, sizeof(f), hipMemcpyHostToDevice, e->stream));
-    CK(launch_pack_frag_qkv(e->stream, (const bf16_t*)wqkv, wd, Hq, Hkv, H));
-    CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
+    RET(op_weight(e, sc, (const bf16_t*)wqkv, (int64_t)(Hq + 2 * Hkv) * 128, H, Hq, Hkv, true, fp8, &wd, &wscale));
+    CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
                       (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
@@ -1409,44 +1495,47 @@ int dots_op_decode_attn(DotsEngine* e, const void* q, const void* pool_layer, co
     return DOTS_OK;
 }
 
-int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout, int B, int N, int K) {
+int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout, int B, int N, int K, int fp8) {
     if (!e || !x || !w || !h_inout || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_proj arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
-    bf16_t *xi = nullptr, *wd = nullptr;
+    bf16_t* xi = nullptr;
+    void* wd = nullptr;
+    float* wscale = nullptr;
     CK(sc.get(&xi, (size_t)16 * K));
-    CK(sc.get(&wd, (size_t)N * K));
     CK(launch_pack_x(e->stream, (const bf16_t*)x, xi, B, K));
-    CK(launch_pack_frag(e->stream, (const bf16_t*)w, wd, N, K));
-    CK(launch_dec_proj(e->stream, xi, wd, (bf16_t*)h_inout, B, N, K));
+    RET(op_weight(e, sc, (const bf16_t*)w, N, K, 0, 0, false, fp8, &wd, &wscale));
+    CK(launch_dec_proj(e->stream, xi, wd, wscale, (bf16_t*)h_inout, B, N, K));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
 
-int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const void* gate_w, const void* up_w, void* act_out, int B, int H, int I, float eps) {
+int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const void* gate_w, const void* up_w, void* act_out, int B, int H, int I, float eps,
+                       int fp8) {
     if (!e || !h || !ln_w || !gate_w || !up_w || !act_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_gateup arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
-    bf16_t *w13 = nullptr, *w13d = nullptr, *act = nullptr;
+    bf16_t *w13 = nullptr, *act = nullptr;
+    void* w13d = nullptr;
+    float* wscale = nullptr;
     CK(sc.get(&w13, (size_t)2 * I * H));
-    CK(sc.get(&w13d, (size_t)2 * I * H));
     CK(sc.get(&act, (size_t)16 * I));
     CK(launch_pack_w13(e->stream, (const bf16_t*)gate_w, (const bf16_t*)up_w, w13, I, H));
-    CK(launch_pack_frag(e->stream, w13, w13d, 2 * I, H));
-    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, act, B, H, I, eps));
+    RET(op_weight(e, sc, w13, (int64_t)2 * I, H, 0, 0, false, fp8, &w13d, &wscale));
+    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps));
     CK(launch_unpack_x(e->stream, act, (bf16_t*)act_out, B, I));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
 
-int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const void* w, void* logits_out, int B, int H, int V, float eps) {
+int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const void* w, void* logits_out, int B, int H, int V, float eps, int fp8) {
     if (!e || !h || !ln_w || !w || !logits_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_lmhead arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
-    bf16_t* wd = nullptr;
-    CK(sc.get(&wd, (size_t)V * H));
-    CK(launch_pack_frag(e->stream, (const bf16_t*)w, wd, V, H));
-    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, (float*)logits_out, B, H, V, eps));
+    void* wd = nullptr;
+    float* wscale = nullptr;
+    RET(op_weight(e, sc, (const bf16_t*)w, V, H, 0, 0, false, fp8, &wd, &wscale));
+    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (float*)logits_out, B, H, V, eps));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

@@ -36,8 +36,8 @@ DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
 // ---- epilogue shared by both tile shapes: lane owns (m, 4 consecutive n) per (fn, fm, rq) of its 64x64 wave tile.
 // nw0 = first weight row (n) of the wave tile, mw0 = first activation row (m) of the wave tile.
 template <int EPI, int FN>
-DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ bias, const bf16_t* R, void* Cout,
-                        int M, int ldc, int nw0, int mw0, int l31, int hi) {
+DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
+                        void* Cout, int M, int ldc, int nw0, int mw0, int l31, int hi) {
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm) {
         const int m = mw0 + fm * 32 + l31;
@@ -53,6 +53,7 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float g = acc[2 * fp][fm][4 * rq + e], u = acc[2 * fp + 1][fm][4 * rq + e];
+                    if (colscale) { g *= colscale[nb + e]; u *= colscale[nb + 32 + e]; }       // fp8 weights: per-output-channel scale (quant.hip)
                     if (bias) { g += bf2f(bias[nb + e]); u += bf2f(bias[nb + 32 + e]); }
                     o[e] = silu(g) * u;
                 }
@@ -69,6 +70,11 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[fn][fm][4 * rq + e];
+                    if (colscale) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(colscale + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+                    }
                     if (bias) {
                         u32x2 bb = *reinterpret_cast<const u32x2*>(bias + nb);
                         o[0] += lo_bf(bb[0]); o[1] += hi_bf(bb[0]); o[2] += lo_bf(bb[1]); o[3] += hi_bf(bb[1]);
@@ -96,7 +102,7 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
-    const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
 
     const int tid = threadIdx.x;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
         }
     }
 
-    gemm_epilogue<EPI, 2>(acc, bias, R, Cout, M, ldc, n0 + wn * 64, m0 + wm * 64, l31, hi);
+    gemm_epilogue<EPI, 2>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 64, m0 + wm * 64, l31, hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +201,7 @@ constexpr int OP2_BYTES = 256 * 128, STAGE2 = 2 * OP2_BYTES;
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
-    const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
 
     const int tid = threadIdx.x;
@@ -278,13 +284,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    gemm_epilogue<EPI, 4>(acc, bias, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 64, l31, hi);
+    gemm_epilogue<EPI, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 64, l31, hi);
 }
 
 }  // namespace
 
 template <int E>
-static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R, void* C,
+static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const float* colscale, const bf16_t* R, void* C,
                                 int M, int N, int K, int lda, int ldc) {
     // dynamic LDS > 64 KB is opted into once per (instantiation, DEVICE): engines on several GPUs may live in one process
     static uint32_t configured = 0;
@@ -298,30 +304,30 @@ static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, co
         __atomic_fetch_or(&configured, bit, __ATOMIC_RELEASE);
     }
     const int m_tiles = (M + BM2 - 1) / BM2, n_tiles = N / BN2;
-    hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, R, C, M, N, K,
+    hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, colscale, R, C, M, N, K,
                        lda, ldc, m_tiles, n_tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R,
-                       void* C, int64_t M, int N, int K, int lda, int ldc, int epi) {
+                       void* C, int64_t M, int N, int K, int lda, int ldc, int epi, const float* colscale) {
     if (M <= 0) return hipSuccess;
     if (N % BN != 0 || K % BK != 0 || (lda % 8) != 0 || (ldc % 4) != 0) return hipErrorInvalidValue;
     static const bool force_small = getenv("DOTS_OCR_GEMM_128") != nullptr;
     if (N % BN2 == 0 && !force_small) {
         switch (epi) {
-            case EPI_NONE: return launch_256<EPI_NONE>(s, A, W, bias, R, C, (int)M, N, K, lda, ldc);
-            case EPI_RESIDUAL: return launch_256<EPI_RESIDUAL>(s, A, W, bias, R, C, (int)M, N, K, lda, ldc);
-            case EPI_SWIGLU: return launch_256<EPI_SWIGLU>(s, A, W, bias, R, C, (int)M, N, K, lda, ldc);
-            case EPI_GELU: return launch_256<EPI_GELU>(s, A, W, bias, R, C, (int)M, N, K, lda, ldc);
-            case EPI_F32: return launch_256<EPI_F32>(s, A, W, bias, R, C, (int)M, N, K, lda, ldc);
+            case EPI_NONE: return launch_256<EPI_NONE>(s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc);
+            case EPI_RESIDUAL: return launch_256<EPI_RESIDUAL>(s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc);
+            case EPI_SWIGLU: return launch_256<EPI_SWIGLU>(s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc);
+            case EPI_GELU: return launch_256<EPI_GELU>(s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc);
+            case EPI_F32: return launch_256<EPI_F32>(s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc);
             default: return hipErrorInvalidValue;
         }
     }
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = N / BN;
     dim3 grid(m_tiles * n_tiles), block(256);
 #define LAUNCH(E)                                                                                       \
-    hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, 0, s, A, W, bias, R, C, (int)M, N, K, lda, ldc, \
+    hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, 0, s, A, W, bias, colscale, R, C, (int)M, N, K, lda, ldc, \
                        m_tiles, n_tiles)
     switch (epi) {
         case EPI_NONE: LAUNCH(EPI_NONE); break;

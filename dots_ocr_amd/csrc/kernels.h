@@ -9,7 +9,8 @@ enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4
 
 // ---- gemm.hip
 hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R,
-                       void* C, int64_t M, int N, int K, int lda, int ldc, int epi);
+                       void* C, int64_t M, int N, int K, int lda, int ldc, int epi, const float* colscale = nullptr);
+// colscale: fp32 [N] multiplied into the accumulator column before bias (fp8 weights: W holds bf16(q), quant.hip), or nullptr
 
 // ---- elementwise.hip
 hipError_t launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int dim, float eps);
@@ -45,13 +46,15 @@ hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv,
 // ---- decode_fused.hip: dense layers of the decode step with in-workgroup split-K and fused prologues/epilogues.
 // Activations between them travel as X images [K/8][XR][8], XR = 8 (B <= 8) or 16 (decode_layout.h).
 hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* embed, bf16_t* h, int B, int dim);
-hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, const bf16_t* bias,
+// Wd + wscale: wscale == nullptr -> Wd is the bf16 fragment image (launch_pack_frag*); else Wd is the e4m3 fragment image
+// (launch_pack_frag_fp8) and wscale[row] its fp32 per-output-channel scales (quant.hip).
+hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps);
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const bf16_t* Wd, bf16_t* h, int B, int N, int K);       // h += X @ W^T
-hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* W13d, bf16_t* act,
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K);   // h += X @ W^T
+hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
                              int B, int H, int I, float eps);
-hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const bf16_t* Wd, float* logits,
+hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
                              int B, int H, int V, float eps);
 int decode_attn_waves();                       // pages in flight per decode-attention workgroup (engine constant)
 int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
@@ -78,6 +81,11 @@ hipError_t launch_pack_frag_qkv(hipStream_t s, const bf16_t* src, bf16_t* dst, i
 // row-major [rows <= 16, K] <-> X image [K/8][XR][8] (XR = 8 for rows <= 8, else 16): the single-kernel entry points' converters
 hipError_t launch_pack_x(hipStream_t s, const bf16_t* src, bf16_t* x, int rows, int K);
 hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows, int K);
+// ---- quant.hip: fp8 (e4m3, per-output-channel scale) weights
+// W[n][:] <- bf16(e4m3(W[n][:] / scale[n])) in place, scale[n] = max|W[n][:]| / 448 (1 for an all-zero row)
+hipError_t launch_quant_rows_fp8(hipStream_t s, bf16_t* W, float* scale, int64_t N, int K);
+// bf16(q) row-major [rows, K] -> e4m3 bytes in decode fragment order (512-B chunks); rot_rows = (Hq + Hkv) * 128 for the fused qkv weight, else 0
+hipError_t launch_pack_frag_fp8(hipStream_t s, const bf16_t* src, uint8_t* dst, int64_t rows, int K, int rot_rows);
 // ---- engine.hip helper kernels
 hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
 hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);

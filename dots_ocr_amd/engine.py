@@ -29,6 +29,7 @@ class CDotsConfig(C.Structure):
         ("v_use_bias", C.c_int32), ("v_post_norm", C.c_int32),
         ("max_batch", C.c_int32), ("max_seq_len", C.c_int32),
         ("max_patches", C.c_int64), ("max_prefill_tokens", C.c_int64), ("kv_pool_tokens", C.c_int64),
+        ("fp8_weights", C.c_int32), ("_reserved", C.c_int32),
     ]
 
 
@@ -89,14 +90,15 @@ def _prototypes(lib):
         "dots_memcpy_d2h": (i32, [vp, vp, vp, i64]),
         "dots_op_rmsnorm": (i32, [vp, vp, vp, vp, i64, i32, f32]),
         "dots_op_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),
-        "dots_op_gemm": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]),
+        "dots_op_gemm": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+        "dots_op_quant_fp8": (i32, [vp, vp, vp, i64, i32]),
         "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
         "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
-        "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32]),
+        "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32]),
         "dots_op_decode_attn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32]),
-        "dots_op_dec_proj": (i32, [vp, vp, vp, vp, i32, i32, i32]),
-        "dots_op_dec_gateup": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32]),
-        "dots_op_dec_lmhead": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32]),
+        "dots_op_dec_proj": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
+        "dots_op_dec_gateup": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
+        "dots_op_dec_lmhead": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32]),
         "dots_probe_mfma": (i32, [i32, vp, vp, vp, vp]),
         "dots_probe_grid_barrier": (i32, [i32, i32, i32, i32, i32, P(f32), P(i32)]),
         "dots_probe_cu_mask": (i32, [P(C.c_uint32), i32, i32, i32, i32, P(C.c_uint32)]),
@@ -114,13 +116,14 @@ EXPORTED_SYMBOLS = [
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
-    "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm",
+    "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
     "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
 
 
-def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int, max_prefill_tokens: int, kv_pool_tokens: int = 0) -> CDotsConfig:
+def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int, max_prefill_tokens: int, kv_pool_tokens: int = 0,
+             fp8_weights: bool = False) -> CDotsConfig:
     v = cfg.vision
     return CDotsConfig(
         hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers, num_heads=cfg.num_attention_heads,
@@ -132,7 +135,7 @@ def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int
         v_channels=v.num_channels, v_temporal_patch=v.temporal_patch_size, v_rms_eps=v.rms_norm_eps,
         v_ln_eps=v.merger_ln_eps, v_use_bias=int(v.use_bias), v_post_norm=int(v.post_norm),
         max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches,
-        max_prefill_tokens=max_prefill_tokens, kv_pool_tokens=kv_pool_tokens)
+        max_prefill_tokens=max_prefill_tokens, kv_pool_tokens=kv_pool_tokens, fp8_weights=int(bool(fp8_weights)))
 
 
 def _i32p(a: np.ndarray):
@@ -147,7 +150,8 @@ class Engine:
     """One GPU, one HIP stream, one model replica."""
 
     def __init__(self, cfg: DotsConfig, device: int = 0, max_batch: int = 8, max_seq_len: int = 8192,
-                 max_patches: int = 8 * 19824 + 64, max_prefill_tokens: Optional[int] = None, kv_pool_tokens: int = 0):
+                 max_patches: int = 8 * 19824 + 64, max_prefill_tokens: Optional[int] = None, kv_pool_tokens: int = 0,
+                 fp8_weights: bool = False):
         self.lib = _lib.load()
         _prototypes(self.lib)
         self.cfg = cfg
@@ -159,7 +163,8 @@ class Engine:
             max_prefill_tokens = max_batch * max_seq_len
         self.max_prefill_tokens = max_prefill_tokens
         self.kv_pool_tokens = kv_pool_tokens
-        self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens, kv_pool_tokens)
+        self.fp8_weights = bool(fp8_weights)
+        self._cc = c_config(cfg, max_batch, max_seq_len, max_patches, max_prefill_tokens, kv_pool_tokens, fp8_weights)
         h = C.c_void_p()
         rc = self.lib.dots_create(C.byref(self._cc), device, C.byref(h))
         if rc != 0:
@@ -392,8 +397,11 @@ class Engine:
     def op_layernorm(self, x, w, b, y, rows, dim, eps):
         self._ck(self.lib.dots_op_layernorm(self.h, x, w, b, y, rows, dim, eps), "dots_op_layernorm")
 
-    def op_gemm(self, A, W, bias, residual, Cout, M, N, K, epilogue=EPI_NONE):
-        self._ck(self.lib.dots_op_gemm(self.h, A, W, bias or None, residual or None, Cout, M, N, K, epilogue), "dots_op_gemm")
+    def op_gemm(self, A, W, bias, residual, Cout, M, N, K, epilogue=EPI_NONE, colscale=None):
+        self._ck(self.lib.dots_op_gemm(self.h, A, W, bias or None, residual or None, Cout, M, N, K, epilogue, colscale or None), "dots_op_gemm")
+
+    def op_quant_fp8(self, w_inout, scale_out, N, K):
+        self._ck(self.lib.dots_op_quant_fp8(self.h, w_inout, scale_out, N, K), "dots_op_quant_fp8")
 
     def op_flash_attn(self, q, k, vt, out, cu_seqlens, Hq, Hkv, causal, scale):
         cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
@@ -407,19 +415,19 @@ class Engine:
                                                  int(rope2d), theta), "dots_op_qkv_rope_split")
 
     # ---- single kernels of the decode step (row-major device tensors; packing happens inside the library)
-    def op_dec_qkv(self, h, ln_w, wqkv, bias, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, rope_theta):
+    def op_dec_qkv(self, h, ln_w, wqkv, bias, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, rope_theta, fp8=False):
         self._ck(self.lib.dots_op_dec_qkv(self.h, h, ln_w, wqkv, bias or None, ctx_len, block_table, max_pages, pool_layer, q_out,
-                                          B, H, Hq, Hkv, eps, rope_theta), "dots_op_dec_qkv")
+                                          B, H, Hq, Hkv, eps, rope_theta, int(fp8)), "dots_op_dec_qkv")
 
     def op_decode_attn(self, q, pool_layer, ctx_len, block_table, max_pages, out, B, Hq, Hkv, max_seq_len):
         self._ck(self.lib.dots_op_decode_attn(self.h, q, pool_layer, ctx_len, block_table, max_pages, out, B, Hq, Hkv, max_seq_len),
                  "dots_op_decode_attn")
 
-    def op_dec_proj(self, x, w, h_inout, B, N, K):
-        self._ck(self.lib.dots_op_dec_proj(self.h, x, w, h_inout, B, N, K), "dots_op_dec_proj")
+    def op_dec_proj(self, x, w, h_inout, B, N, K, fp8=False):
+        self._ck(self.lib.dots_op_dec_proj(self.h, x, w, h_inout, B, N, K, int(fp8)), "dots_op_dec_proj")
 
-    def op_dec_gateup(self, h, ln_w, gate_w, up_w, act_out, B, H, I, eps):
-        self._ck(self.lib.dots_op_dec_gateup(self.h, h, ln_w, gate_w, up_w, act_out, B, H, I, eps), "dots_op_dec_gateup")
+    def op_dec_gateup(self, h, ln_w, gate_w, up_w, act_out, B, H, I, eps, fp8=False):
+        self._ck(self.lib.dots_op_dec_gateup(self.h, h, ln_w, gate_w, up_w, act_out, B, H, I, eps, int(fp8)), "dots_op_dec_gateup")
 
-    def op_dec_lmhead(self, h, ln_w, w, logits_out, B, H, V, eps):
-        self._ck(self.lib.dots_op_dec_lmhead(self.h, h, ln_w, w, logits_out, B, H, V, eps), "dots_op_dec_lmhead")
+    def op_dec_lmhead(self, h, ln_w, w, logits_out, B, H, V, eps, fp8=False):
+        self._ck(self.lib.dots_op_dec_lmhead(self.h, h, ln_w, w, logits_out, B, H, V, eps, int(fp8)), "dots_op_dec_lmhead")

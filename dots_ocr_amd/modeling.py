@@ -53,11 +53,14 @@ def plan_batches(patches_per_seq: Sequence[int], max_batch: int, max_patches: in
 
 class DotsOcrHipForCausalLM:
     def __init__(self, cfg: DotsConfig, state_dict, device: int = 0, max_batch: int = 8, max_seq_len: int = 32768,
-                 max_patches: Optional[int] = None):
+                 max_patches: Optional[int] = None, fp8_weights: bool = False):
+        """fp8_weights: quantise the linears to e4m3 with per-output-channel scales at load time (DotsConfig.fp8_weights of the C ABI;
+        DOTS_OCR_FP8=1 in the environment turns it on for callers that cannot pass the keyword, e.g. DotsOCRParser(use_hf=True))."""
         self.config = cfg
         self.device_index = device
         max_patches = max_patches or max(max_batch * 19824 + 64, 57600 + 64)
-        self.engine = Engine(cfg, device=device, max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches)
+        fp8_weights = bool(fp8_weights) or os.environ.get("DOTS_OCR_FP8", "0") not in ("", "0")
+        self.engine = Engine(cfg, device=device, max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches, fp8_weights=fp8_weights)
         self.engine.load_state_dict(state_dict)
         self.max_batch = max_batch
         self.max_seq_len = max_seq_len

@@ -301,6 +301,7 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--served-model-name", default="model")
     ap.add_argument("--max-batch", type=int, default=8)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--fp8-weights", action="store_true", help="quantise the linears to e4m3 (per-output-channel scale) at load time")
     ap.add_argument("--static-batching", action="store_true", help="static batches through model.generate instead of continuous batching")
     ap.add_argument("--allow-remote-images", action="store_true", help="let requests name http(s) image URLs (off: data: URLs only)")
     ap.add_argument("--allow-local-images", action="store_true", help="let requests name image paths on the server's file system")
@@ -309,10 +310,10 @@ def main(argv: Optional[List[str]] = None):
     from .modeling import DotsOcrHipForCausalLM
     from .processing import DotsOcrProcessor
     if a.random_weights:
-        model = DotsOcrHipForCausalLM.from_random(device=a.device, max_batch=a.max_batch)
+        model = DotsOcrHipForCausalLM.from_random(device=a.device, max_batch=a.max_batch, fp8_weights=a.fp8_weights)
         proc = DotsOcrProcessor(model.config, engine=model.engine)
     else:
-        model = DotsOcrHipForCausalLM.from_pretrained(a.model_path, device=a.device, max_batch=a.max_batch)
+        model = DotsOcrHipForCausalLM.from_pretrained(a.model_path, device=a.device, max_batch=a.max_batch, fp8_weights=a.fp8_weights)
         proc = DotsOcrProcessor.from_pretrained(a.model_path, engine=model.engine)
     uvicorn.run(create_app(model, proc, a.served_model_name, a.max_batch, continuous=not a.static_batching,
                            allow_remote_images=a.allow_remote_images, allow_local_images=a.allow_local_images), host=a.host, port=a.port)

@@ -58,6 +58,11 @@ typedef struct DotsConfig {
     int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
     int64_t kv_pool_tokens;   /* paged KV cache: tokens the page pool holds across ALL sequences (pages of 64); a sequence reserves
                                  prompt + generation cap when it is prefilled.  0 = max_batch * max_seq_len (never refuses) */
+    int32_t fp8_weights;      /* != 0: dots_finalize_weights quantises every ViT-block / merger / LM linear and the lm_head to OCP e4m3 with
+                                 one fp32 scale per output channel (scale = max|row| / 448; csrc/quant.hip).  The decode step streams
+                                 the e4m3 bytes (half the HBM traffic); ViT / prefill GEMMs multiply the same quantised values on the
+                                 bf16 MFMA.  Embedding table, patch embedding, norms and biases stay bf16.  (BASELINE configs[4]) */
+    int32_t _reserved;
 } DotsConfig;
 
 /* Per-phase device time of the last dots_generate / dots_vit_forward / ... call, measured with
@@ -186,7 +191,11 @@ int dots_op_layernorm(DotsEngine* e, const void* x_dev, const void* w_dev, const
  * epilogue: 0 none, 1 += residual (bf16 [M,N], may alias C), 2 SwiGLU (W rows interleaved in
  * 32-row gate/up groups, C is [M,N/2]), 3 exact GELU, 4 fp32 output. */
 int dots_op_gemm(DotsEngine* e, const void* A_dev, const void* W_dev, const void* bias_dev,
-                 const void* residual_dev, void* C_dev, int64_t M, int N, int K, int epilogue);
+                 const void* residual_dev, void* C_dev, int64_t M, int N, int K, int epilogue, const float* colscale_dev);
+/* colscale_dev: NULL, or fp32 [N] multiplied into column n of the accumulator before the bias (the per-output-channel scale of
+ * fp8 weights; W then holds the quantised values).
+ * dots_op_quant_fp8: W bf16 [N,K] -> bf16(e4m3(W[n][:] / scale[n])) in place, scale_out[n] = max|W[n][:]| / 448 (1 for a zero row). */
+int dots_op_quant_fp8(DotsEngine* e, void* w_inout_dev, float* scale_out_dev, int64_t N, int K);
 /* Flash attention over packed sequences.  q [Hq, T, 128], k [Hkv, T, 128] bf16 (head-major),
  * vt [Hkv, 128, Tpad] (V transposed, every sequence padded to 64 keys, keys permuted inside
  * 16-groups as csrc/attn_prefill.hip documents), cu_seqlens int32 [n_seq+1] (host).
@@ -211,17 +220,19 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv_dev, void* q_dev, void
  *                      kernel + combine kernel, KV split = the engine constant derived from max_seq_len) -> out bf16 [B, Hq*128].
  * dots_op_dec_proj     h_inout [B,N] += x [B,K] @ w [N,K]^T   (o_proj / down_proj with the residual add).
  * dots_op_dec_gateup   act_out [B,I] = silu(g) * u with g|u = RMSNorm(h) @ gate_w|up_w [I,H]^T.
- * dots_op_dec_lmhead   logits_out fp32 [B,V] = RMSNorm(h) @ w [V,H]^T. */
+ * dots_op_dec_lmhead   logits_out fp32 [B,V] = RMSNorm(h) @ w [V,H]^T.
+ * fp8 != 0: the weight is quantised (dots_op_quant_fp8 on a copy), packed as e4m3 fragments and streamed by the fp8 instantiation
+ * of the kernel — the path a DotsConfig.fp8_weights engine decodes with. */
 int dots_op_dec_qkv(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* wqkv_dev, const void* bias_dev,
                     const int32_t* ctx_len_dev, const int32_t* block_table_dev, int max_pages, void* pool_layer_dev, void* q_out_dev,
-                    int B, int H, int Hq, int Hkv, float eps, float rope_theta);
+                    int B, int H, int Hq, int Hkv, float eps, float rope_theta, int fp8);
 int dots_op_decode_attn(DotsEngine* e, const void* q_dev, const void* pool_layer_dev, const int32_t* ctx_len_dev,
                         const int32_t* block_table_dev, int max_pages, void* out_dev, int B, int Hq, int Hkv, int max_seq_len);
-int dots_op_dec_proj(DotsEngine* e, const void* x_dev, const void* w_dev, void* h_inout_dev, int B, int N, int K);
+int dots_op_dec_proj(DotsEngine* e, const void* x_dev, const void* w_dev, void* h_inout_dev, int B, int N, int K, int fp8);
 int dots_op_dec_gateup(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* gate_w_dev, const void* up_w_dev, void* act_out_dev,
-                       int B, int H, int I, float eps);
+                       int B, int H, int I, float eps, int fp8);
 int dots_op_dec_lmhead(DotsEngine* e, const void* h_dev, const void* ln_w_dev, const void* w_dev, void* logits_out_dev, int B, int H, int V,
-                       float eps);
+                       float eps, int fp8);
 
 /* MFMA fragment-layout / LDS-DMA probe (csrc/probe_mfma.hip; tests/test_mfma_layout.py). */
 int dots_probe_mfma(int which, const void* A, const void* Bt, void* D, void* stream);

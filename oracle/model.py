@@ -68,6 +68,39 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -
     return y if b is None else y + b
 
 
+# =============================================================================== fp8 weights (BASELINE configs[4])
+def quantize_rows_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N, K] -> (q, scale): OCP e4m3 ("e4m3fn") values q (as fp32) and one fp32 scale per output channel,
+    scale = max|row| / 448 (1 for an all-zero row), q = e4m3(w / scale) with torch's round-to-nearest-even cast.
+    The definition the engine's csrc/quant.hip is tested against (tests/test_fp8_gpu.py)."""
+    w = w.float()
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn).float()
+    return q, scale
+
+
+FP8_LINEAR_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "mlp.fc3.weight",
+                       "merger.mlp.0.weight", "merger.mlp.2.weight",
+                       "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                       "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "lm_head.weight")
+
+
+def quantize_fp8_state_dict(sd: SD) -> SD:
+    """The state dict an fp8_weights engine computes with: every ViT-block / merger / LM linear and the lm_head (a copy of the
+    embedding table when tied) replaced by q * scale in fp32; embeddings, the patch embedding, norms and biases untouched.
+    Running the oracle on it IS the fp8 oracle mode: y = x @ (q * scale)^T differs from the engine's (x @ q^T) * scale by fp32
+    rounding only, and the bf16 storage points of emulate_bf16 are the same as in the bf16 configuration."""
+    out = dict(sd)
+    if "lm_head.weight" not in out:
+        out["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    for name in list(out):
+        if name.endswith(FP8_LINEAR_SUFFIXES) and out[name].dim() == 2:
+            q, scale = quantize_rows_fp8(out[name])
+            out[name] = q * scale[:, None]
+    return out
+
+
 # =============================================================================== vision
 def vision_position_ids(grid_thw: torch.Tensor, merge: int) -> torch.Tensor:
     """(h, w) index of every patch, block-major over merge x merge groups

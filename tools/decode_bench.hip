@@ -88,14 +88,19 @@ int main(int argc, char** argv) {
 #endif
     const int max_pages = (max_seq + 63) / 64;
     const int n_splits = decode_attn_splits(max_seq);
-    // weights: 0x3c3c = bf16 0.0115
-    std::vector<bf16_t*> qkv(L), o(L), w13(L), down(L), ln1(L), ln2(L), bias(L);
+    // weights: 0x3c3c = bf16 0.0115.  DOTS_BENCH_FP8=1: the e4m3 instantiations (1 byte per weight, 0x3c = 1.5; scales 0x3c3c3c3c = 0.0115)
+    const bool fp8 = getenv("DOTS_BENCH_FP8") != nullptr;
+    const size_t wb = fp8 ? 1 : 2;
+    std::vector<bf16_t*> ln1(L), ln2(L), bias(L);
+    std::vector<uint8_t*> qkv(L), o(L), w13(L), down(L);
     for (int i = 0; i < L; ++i) {
-        qkv[i] = dalloc<bf16_t>((size_t)NQKV * H, 0x3c); o[i] = dalloc<bf16_t>((size_t)H * Nq, 0x3c);
-        w13[i] = dalloc<bf16_t>((size_t)2 * I * H, 0x3c); down[i] = dalloc<bf16_t>((size_t)H * I, 0x3c);
+        qkv[i] = dalloc<uint8_t>((size_t)NQKV * H * wb, 0x3c); o[i] = dalloc<uint8_t>((size_t)H * Nq * wb, 0x3c);
+        w13[i] = dalloc<uint8_t>((size_t)2 * I * H * wb, 0x3c); down[i] = dalloc<uint8_t>((size_t)H * I * wb, 0x3c);
         ln1[i] = dalloc<bf16_t>(H, 0x3f); ln2[i] = dalloc<bf16_t>(H, 0x3f); bias[i] = dalloc<bf16_t>(NQKV, 0x3c);
     }
-    bf16_t* lm = dalloc<bf16_t>((size_t)V * H, 0x3c);
+    uint8_t* lm = dalloc<uint8_t>((size_t)V * H * wb, 0x3c);
+    float* wsc = fp8 ? dalloc<float>((size_t)V, 0x3c) : nullptr;
+    printf("weights: %s\n", fp8 ? "e4m3 + per-channel scale" : "bf16");
     bf16_t* embed = dalloc<bf16_t>((size_t)V * H, 0x3c);
     bf16_t* fnorm = dalloc<bf16_t>(H, 0x3f);
     const size_t pool_layer = (size_t)B * max_pages * Hkv * 2 * 8192;
@@ -120,13 +125,13 @@ int main(int argc, char** argv) {
     st.cur_tokens = cur; st.ctx_len = ctx_len; st.out_ids = out_ids; st.out_lens = out_lens; st.finished = fin; st.eos_ids = nullptr; st.sel = nullptr;
     st.max_len = nullptr; st.n_eos = 0; st.out_stride = 64; st.cap = 1; st.advance_ctx = 0;       // cap 1: rows finish at once, ctx stays put
 
-    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps)); };
+    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps)); };
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
-    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], h0, B, H, Nq)); };
-    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], act, B, H, I, eps)); };
-    auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], h0, B, H, I)); };
-    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, logits, B, H, V, eps)); };
+    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq)); };
+    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps)); };
+    auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I)); };
+    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps)); };
     // skip: bit mask of kernel kinds left out (marginal cost of a kind inside the real, HBM-cold step = full - skipped)
     auto step_skip = [&](int skip) {
         CK(launch_dec_embed(S, cur, embed, h0, B, H));
@@ -142,7 +147,7 @@ int main(int argc, char** argv) {
         CK(launch_argmax_step(S, logits, V, V, B, am_val, am_idx, st));
     };
     auto step = [&]() { step_skip(0); };
-    const double w_bytes = 2.0 * (L * ((double)NQKV * H + (double)Nq * H + 3.0 * H * I) + (double)V * H);
+    const double w_bytes = (double)wb * (L * ((double)NQKV * H + (double)Nq * H + 3.0 * H * I) + (double)V * H);
     const double kv_bytes = (double)B * (ctx + 1) * L * Hkv * 128 * 2 * 2;
     printf("decode_bench: B=%d ctx=%d max_seq_len=%d (n_splits %d); algorithmic bytes/step %.1f MB weights + %.1f MB KV\n", B, ctx, max_seq, n_splits,
            w_bytes / 1e6, kv_bytes / 1e6);
@@ -156,7 +161,7 @@ int main(int argc, char** argv) {
            (w_bytes + kv_bytes) / t_step / 1e6 / 8 * 100);
     {
         const char* names[] = {"dec_qkv", "decode_attn", "decode_attn_combine", "dec_proj o", "dec_gateup", "dec_proj down", "dec_lmhead"};
-        const double mbs[] = {2.0 * NQKV * H / 1e6, kv_bytes / L / 1e6, 0, 2.0 * Nq * H / 1e6, 4.0 * I * H / 1e6, 2.0 * I * H / 1e6, 2.0 * V * H / 1e6};
+        const double mbs[] = {wb * 1.0 * NQKV * H / 1e6, kv_bytes / L / 1e6, 0, wb * 1.0 * Nq * H / 1e6, wb * 2.0 * I * H / 1e6, wb * 1.0 * I * H / 1e6, wb * 1.0 * V * H / 1e6};
         double tot = 0;
         for (int k = 0; k < 7; ++k) {
             const double t = time_graph([&]() { step_skip(1 << k); });
@@ -168,12 +173,12 @@ int main(int argc, char** argv) {
     }
     struct Row { const char* name; std::function<void(int)> fn; double mb; };
     const Row rows[] = {
-        {"dec_qkv", k_qkv, 2.0 * NQKV * H / 1e6},
+        {"dec_qkv", k_qkv, wb * 1.0 * NQKV * H / 1e6},
         {"decode_attn", k_attn, kv_bytes / L / 1e6},
         {"decode_attn_combine", k_comb, 0},
-        {"dec_proj o", k_o, 2.0 * Nq * H / 1e6},
-        {"dec_gateup", k_gu, 4.0 * I * H / 1e6},
-        {"dec_proj down", k_down, 2.0 * I * H / 1e6},
+        {"dec_proj o", k_o, wb * 1.0 * Nq * H / 1e6},
+        {"dec_gateup", k_gu, wb * 2.0 * I * H / 1e6},
+        {"dec_proj down", k_down, wb * 1.0 * I * H / 1e6},
     };
     double sum = 0;
     for (const Row& r : rows) {
@@ -182,7 +187,7 @@ int main(int argc, char** argv) {
         trace_report(r.name, 8);
     }
     const double lm_us = time_graph([&]() { for (int i = 0; i < 4; ++i) k_lm(); }) / 4;
-    printf("%-24s %8.2f us / launch   %6.1f MB   %.2f TB/s\n", "dec_lmhead", lm_us, 2.0 * V * H / 1e6, 2.0 * V * H / 1e6 / lm_us);
+    printf("%-24s %8.2f us / launch   %6.1f MB   %.2f TB/s\n", "dec_lmhead", lm_us, wb * 1.0 * V * H / 1e6, wb * 1.0 * V * H / 1e6 / lm_us);
     const double misc = time_graph([&]() { for (int i = 0; i < 8; ++i) { CK(launch_dec_embed(S, cur, embed, h0, B, H)); CK(launch_argmax_step(S, logits, V, V, B, am_val, am_idx, st)); } }) / 8;
     printf("%-24s %8.2f us (embed + argmax partial + argmax step)\n", "step glue", misc);
     return 0;
