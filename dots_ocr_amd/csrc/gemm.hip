@@ -99,6 +99,74 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
     }
 }
 
+// ---- epilogue of the 256 x 256 kernels, staged through LDS.  The direct epilogue above stores 8 bytes per lane at a row stride
+// (32 partial lines per store instruction; measured 17 % of the GEMM time at K = 1536: tools/gemm_bench.py, -DPP_NO_STORE).
+// Here each wave transposes one 32(m) x 128(n) fp32 half of its tile through its own 16 KB of the (now idle) pipeline stages and
+// writes whole lines: a lane owns 8 consecutive n of one row -> 16-byte stores, 4 rows x 256 B per instruction; residual reads
+// are coalesced the same way.  Same arithmetic as gemm_epilogue (fp32: * colscale, + bias, + residual, activation, ONE rounding).
+// LDS image [32 rows][32 slots of 16 B], slot ^= (row & 15) << 1: conflict-free ds_write_b128 (8 consecutive rows per group),
+// and the slot pair (2k, 2k + 1) of a lane's 8 floats stays adjacent.  Private to the wave: no barrier, LDS ops of one wave are
+// executed in order.
+template <int EPI>
+DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
+                            bf16_t* __restrict__ C, int M, int ldc, int nw0, int mw0, int l, char* stage) {
+    const int hi = l >> 5, l31 = l & 31;
+    constexpr bool SW = EPI == EPI_SWIGLU;
+    // read-side geometry: plain: 4 rows x 16 lanes (8 n each); SwiGLU: 8 rows x 8 lanes (8 outputs each = 8 gate + 8 up inputs)
+    const int rrow = SW ? (l >> 3) : (l >> 4);
+    const int gcol = SW ? ((l & 7) >> 2) * 64 + (l & 3) * 8 : (l & 15) * 8;          // first of the lane's 8 (gate) columns in the wave tile
+    float sc0[8], sc1[8], bi0[8], bi1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc0[e] = colscale ? colscale[nw0 + gcol + e] : 1.f;
+        bi0[e] = bias ? bf2f(bias[nw0 + gcol + e]) : 0.f;
+        sc1[e] = (SW && colscale) ? colscale[nw0 + gcol + 32 + e] : 1.f;
+        bi1[e] = (SW && bias) ? bf2f(bias[nw0 + gcol + 32 + e]) : 0.f;
+    }
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int slot = (fn * 8 + rq * 2 + hi) ^ ((l31 & 15) << 1);
+                const f32x4 v = {acc[fn][fm][4 * rq], acc[fn][fm][4 * rq + 1], acc[fn][fm][4 * rq + 2], acc[fn][fm][4 * rq + 3]};
+                *reinterpret_cast<f32x4*>(stage + l31 * 512 + slot * 16) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < (SW ? 4 : 8); ++it) {
+            const int row = it * (SW ? 8 : 4) + rrow;
+            const int m = mw0 + fm * 32 + row;
+            const int sw = (row & 15) << 1;
+            const char* rp = stage + row * 512;
+            const int s0 = gcol >> 2;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ sw) << 4)), a1 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 1) ^ sw) << 4));
+            float o[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * sc0[e] + bi0[e];
+            if constexpr (SW) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 8) ^ sw) << 4)), u1 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 9) ^ sw) << 4));
+                const float u[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = silu(o[e]) * (u[e] * sc1[e] + bi1[e]);
+            }
+            if (m >= M) continue;
+            const int col = SW ? nw0 / 2 + ((l & 7) >> 2) * 32 + (l & 3) * 8 : nw0 + gcol;
+            if constexpr (EPI == EPI_RESIDUAL) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(R + (size_t)m * ldc + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] += lo_bf(rr[e]); o[2 * e + 1] += hi_bf(rr[e]); }
+            }
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = gelu_erf(o[e]);
+            }
+            const u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + col) = pk;
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
@@ -287,6 +355,158 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(
     gemm_epilogue<EPI, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 64, l31, hi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256 x 256 tile (same wave tiles, same epilogue): K is cut into SUB-TILES of 32 (16 MFMAs per wave),
+// four LDS stages of 32 KB, and the two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run half a sub-tile period
+// apart: while one group issues its 16 MFMAs the other fetches its 12 operand fragments from LDS and issues its 4 DMA pieces,
+// then they swap.  Per group and sub-tile p:
+//     L(p): 12 ds_read_b128 of sub-tile p | 4 DMA pieces of sub-tile p + 3 | vmcnt -> own pieces of p + 1 landed | lgkmcnt(0) | barrier
+//     M(p): 16 MFMAs at raised priority                                                                                     | barrier
+// and group 1 passes one extra barrier first, so its L(p) coincides with group 0's M(p).  The lock-step kernel above loses the
+// MFMA pipe at every K-tile to barrier skew + the first fragments' LDS latency (48 % MFMA-busy, waves 36 % parked:
+// profiles/r01_pmc_flash_gemm.json); here the pipe always has one wave per SIMD inside an MFMA cluster.
+// Ordering: a sub-tile is read one full part after every wave waited for its own DMA pieces and passed a barrier; its stage is
+// re-filled (sub-tile p + 3 -> stage (p - 1) & 3) only after the barrier that follows group 1's last read of sub-tile p - 1.
+// LDS image of a sub-tile operand: 256 rows x 64 B, 16-B slot XOR ((row >> 2) & 3): the 16 lanes of a ds_read_b128 group
+// (rows 0-3, 12-15, 20-27 / 4-11, 16-19, 28-31) land on 16 distinct slots of the 256-B bank row; applied on the DMA source
+// side (piece = 16 rows x 64 B, lane l = row l >> 2, slot l & 3) and again on the read.
+#define PINV(x) asm volatile("" ::"v"(x))
+constexpr int SUBK = 32, SUB_OP = 256 * 64, SUB_STAGE = 2 * SUB_OP, PP_STAGES = 4, PP_LOOKAHEAD = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = l >> 5, l31 = l & 31;
+    const int grp = w >> 2;                                     // waves w and w + 4 share a SIMD
+
+    int bid = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int per_group = GROUP_M * n_tiles;
+    const int g = bid / per_group;
+    const int first_m = g * GROUP_M;
+    const int gsz = min(m_tiles - first_m, GROUP_M);
+    const int in_grp = bid - g * per_group;
+    const int tm = first_m + in_grp % gsz;
+    const int tn = in_grp / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // DMA pieces (16 rows x 64 B = 1 KiB): 16 per operand and sub-tile, wave w takes pieces w and w + 8
+    const bf16_t* gw[2];
+    const bf16_t* gx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + w) * 16 + (l >> 2);
+        const int slot = (l & 3) ^ ((l >> 4) & 3);             // = (l & 3) ^ ((row >> 2) & 3)
+        gw[i] = W + (size_t)(n0 + row) * K + slot * 8;
+        gx[i] = A + (size_t)min(m0 + row, M - 1) * lda + slot * 8;
+    }
+    auto issue_sub = [&](int p) {
+        char* base = smem2 + (p & (PP_STAGES - 1)) * SUB_STAGE;
+#ifdef PP_DMA_SAME
+        p &= 1;                                                 // timing experiment: every DMA hits L2
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + p * SUBK),
+                                             (__attribute__((address_space(3))) void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[i] + p * SUBK),
+                                             (__attribute__((address_space(3))) void*)(base + SUB_OP + (i * 8 + w) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wn = w >> 2, wm = w & 3;                          // 2 x 4 waves: group 0 = the first 128 weight rows
+    const int rsw = (l31 >> 2) & 3;
+    const int a_off = (wn * 128 + l31) * 64;                    // + fn * 32 * 64
+    const int b_off = SUB_OP + (wm * 64 + l31) * 64;            // + fm * 32 * 64
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ns = K / SUBK;
+    // prologue: sub-tiles 0 .. 2 requested, sub-tile 0 landed
+    issue_sub(0);
+    if (ns > 1) issue_sub(1);
+    if (ns > 2) issue_sub(2);
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ns > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                 // half a period behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int p = 0; p < ns; ++p) {
+        // ---- L(p)
+        const char* base = smem2 + (p & (PP_STAGES - 1)) * SUB_STAGE;
+        bf16x8 af[2][4], bf_[2][2];
+#ifdef PP_NO_LDS
+        if (p == 0)
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ((ks * 2 + hi) ^ rsw) << 4;
+            bf_[ks][0] = *reinterpret_cast<const bf16x8*>(base + b_off + slot);
+            bf_[ks][1] = *reinterpret_cast<const bf16x8*>(base + b_off + 32 * 64 + slot);
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) af[ks][fn] = *reinterpret_cast<const bf16x8*>(base + a_off + fn * 32 * 64 + slot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PP_NO_DMA
+        if (false) {
+#else
+        if (p + PP_LOOKAHEAD < ns) {
+#endif
+            issue_sub(p + PP_LOOKAHEAD);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // own pieces of sub-tile p + 1 landed (p + 2, p + 3 may fly)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M(p)
+        __builtin_amdgcn_s_setprio(1);
+#ifdef PP_NO_MFMA
+        if (p == 0)
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) {
+                acc[fn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][fn], bf_[ks][0], acc[fn][0], 0, 0, 0);
+                acc[fn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][fn], bf_[ks][1], acc[fn][1], 0, 0, 0);
+            }
+#ifdef PP_NO_MFMA
+        else { PINV(af[0][0]); PINV(af[1][3]); PINV(bf_[0][0]); PINV(bf_[1][1]); }
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0 || p + 1 < ns) __builtin_amdgcn_s_barrier();          // group 1 ran one extra barrier at the start
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef PP_NO_STORE
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { PINV(acc[i][0]); PINV(acc[i][1]); }
+#else
+    if constexpr (EPI == EPI_F32 || EPI == EPI_SWIGLU) {      // SwiGLU halves the output bytes: the direct epilogue measured faster there
+        gemm_epilogue<EPI, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 64, l31, hi);
+    } else {
+        __syncthreads();                                        // every wave is done reading the pipeline stages (group 1 skipped its last barrier)
+        gemm_epilogue_lds<EPI>(acc, bias, colscale, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 64, l, smem2 + w * 16384);
+    }
+#endif
+}
+
 }  // namespace
 
 template <int E>
@@ -304,7 +524,20 @@ static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, co
         __atomic_fetch_or(&configured, bit, __ATOMIC_RELEASE);
     }
     const int m_tiles = (M + BM2 - 1) / BM2, n_tiles = N / BN2;
-    hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, colscale, R, C, M, N, K,
+    static const bool lockstep = getenv("DOTS_OCR_GEMM_LOCKSTEP") != nullptr;       // A/B switch: the one-barrier-per-K-tile schedule
+    if (lockstep || ldc % 8 != 0) {                 // the LDS-staged epilogue stores 16 bytes per lane
+        hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, colscale, R, C, M, N, K,
+                           lda, ldc, m_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    static uint32_t configured_pp = 0;
+    if (!(__atomic_load_n(&configured_pp, __ATOMIC_ACQUIRE) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_256pp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PP_STAGES * SUB_STAGE);
+        if (e != hipSuccess) return e;
+        __atomic_fetch_or(&configured_pp, bit, __ATOMIC_RELEASE);
+    }
+    hipLaunchKernelGGL(gemm_bf16_256pp_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), PP_STAGES * SUB_STAGE, s, A, W, bias, colscale, R, C, M, N, K,
                        lda, ldc, m_tiles, n_tiles);
     return hipGetLastError();
 }

@@ -72,7 +72,8 @@ def _pack_w13(gate, up):
     return torch.stack([gate.view(I // 32, 32, K), up.view(I // 32, 32, K)], dim=1).reshape(2 * I, K)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 256, 128), (1000, 384, 640), (129, 1536, 1536), (4097, 128, 4224)])
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 256, 128), (1000, 384, 640), (129, 1536, 1536), (4097, 128, 4224),
+                                   (257, 512, 64), (513, 768, 192), (255, 256, 320)])      # 2 / 6 / 10 K sub-tiles of the 256-wide kernel
 @pytest.mark.parametrize("epi", [0, 1, 3, 4])
 def test_gemm(eng, M, N, K, epi):
     from dots_ocr_amd import engine as E
@@ -97,6 +98,26 @@ def test_gemm(eng, M, N, K, epi):
     # transpose detection: the reference is not symmetric
     if M == N:
         assert (out.float().cpu() - ref.t()).abs().max() > 0.1
+
+
+def test_gemm_vit_shape_is_repeatable_and_exact_everywhere(eng):
+    """The ping-pong schedule orders LDS-DMA writes and ds_reads by counted vmcnt + barriers only: a race would show up as rare
+    wrong tiles that come and go.  A ViT-shaped GEMM (48 K sub-tiles, 180 workgroups) run 6 times must be bit-identical every
+    time and equal to the fp32 reference at EVERY element."""
+    g = torch.Generator().manual_seed(99)
+    M, N, K = 5000, 2304, 1536
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    ref = bf(A.float() @ W.float().t())
+    Ad, Wd = dev(A), dev(W)
+    outs = []
+    for _ in range(6):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        run(eng, eng.op_gemm, Ad.data_ptr(), Wd.data_ptr(), 0, 0, out.data_ptr(), M, N, K, 0)
+        outs.append(out.cpu())
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), "GEMM result changes between runs"
+    close(outs[0], ref)
 
 
 def test_gemm_residual_in_place_and_no_bias(eng):
