@@ -461,3 +461,54 @@ def test_demo_hf_twin_runs_every_prompt_mode():
     from dots_ocr.utils import dict_promptmode_to_prompt
     assert [r[0] for r in rows] == list(dict_promptmode_to_prompt) and all(1 <= r[2] <= 16 for r in rows)
     assert all(r[1] > 19520 // 4 for r in rows)          # demo_image1.jpg's size: 1700 x 2250 -> 19 520 patches -> 4 880 vision tokens
+
+
+def test_openai_server_on_the_real_engine_equals_direct_generate():
+    """SURVEY §8(f) row 3 on the GPU (the server was only CPU-tested on a stand-in model): the FastAPI app over the
+    real engine with continuous batching, driven with the reference client's wire format (dots_ocr/model/inference.py:23-43):
+    6 concurrent greedy requests over 4 slots return exactly what model.generate returns for the same page + prompt."""
+    import threading
+    fastapi = pytest.importorskip("fastapi")  # noqa: F841
+    from fastapi.testclient import TestClient
+    from dots_ocr_amd.config import DotsConfig
+    from dots_ocr_amd.image_utils import PILimage_to_base64
+    from dots_ocr_amd.modeling import DotsOcrHipForCausalLM
+    from dots_ocr_amd.processing import DotsOcrProcessor
+    from dots_ocr_amd.server import create_app
+    from dots_ocr_amd.synthetic import synth_page
+    from dots_ocr_amd.weights import random_state_dict
+    cfg = DotsConfig.tiny(layers=2, v_layers=2)
+    model = DotsOcrHipForCausalLM(cfg, random_state_dict(cfg, seed=11), device=0, max_batch=4, max_seq_len=1024, max_patches=4096)
+    proc = DotsOcrProcessor(cfg, engine=model.engine)
+    prompt = "Extract the text content from this image."
+    pages = [synth_page(i, (224, 140 + 28 * (i % 3))) for i in range(6)]
+    n_new = 12
+
+    def direct(page):
+        messages = [{"role": "user", "content": [{"type": "image", "image": page}, {"type": "text", "text": prompt}]}]
+        text = proc.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        inputs = proc(text=[text], images=[page], padding=True, return_tensors="pt").to("cuda")
+        out = model.generate(**inputs, max_new_tokens=n_new)             # the checkpoint's EOS ids, like the server
+        return proc.batch_decode([out[0, inputs.input_ids.shape[1]:]], skip_special_tokens=True)[0]
+    want = [direct(p) for p in pages]
+
+    app = create_app(model, proc, model_name="model", max_batch=4, max_wait_ms=20)
+    got = [None] * len(pages)
+    with TestClient(app) as c:
+        assert c.get("/health").json() == {"status": "ok"}
+
+        def go(i):
+            body = {"model": "model", "messages": [{"role": "user", "content": [
+                {"type": "image_url", "image_url": {"url": PILimage_to_base64(pages[i])}},
+                {"type": "text", "text": f"<|img|><|imgpad|><|endofimg|>{prompt}"}]}],
+                "max_completion_tokens": n_new, "temperature": 0.0, "top_p": 1.0}
+            r = c.post("/v1/chat/completions", json=body)
+            got[i] = (r.status_code, r.json())
+        th = [threading.Thread(target=go, args=(i,)) for i in range(len(pages))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    for i, (code, d) in enumerate(got):
+        assert code == 200, d
+        assert d["choices"][0]["message"]["content"] == want[i], f"request {i}: server text differs from model.generate"
+        assert 0 < d["usage"]["completion_tokens"] <= n_new and d["choices"][0]["finish_reason"] in ("length", "stop")
+    model.engine.close()
