@@ -439,3 +439,23 @@ def test_post_process_output_salvages_truncated_generation():
     assert filtered and out == "first\n\nsecond"
     cells, filtered = post_process_output('[{"bbox": [1, 2, 30, 40], "category": "Text", "text": "ok"}]', "prompt_layout_all_en", img, img)
     assert not filtered and cells[0]["text"] == "ok"
+
+
+def test_demo_display_helpers_resize_like_the_reference(tmp_path):
+    """dots_ocr.utils.demo_utils.display.read_image (imported by the reference's demo UIs; reference display.py:27-62): longer side
+    -> 1024 (or kept with use_native), the other side truncated, original size returned; sizes checked against values computed by
+    the reference function in this container."""
+    from PIL import Image
+    from dots_ocr.utils.demo_utils.display import is_valid_image_path, read_image
+    want = {(300, 200): (1024, 682), (200, 300): (682, 1024), (256, 256): (1024, 1024), (1999, 777): (1024, 398)}
+    for (w, h), size in want.items():
+        p = tmp_path / f"im_{w}x{h}.png"
+        Image.new("RGB", (w, h), (1, 2, 3)).save(p)
+        img, ow, oh = read_image(str(p))
+        assert img.size == size and (ow, oh) == (w, h)
+        img, ow, oh = read_image(str(p), use_native=True)
+        assert max(img.size) == max(w, h) and (ow, oh) == (w, h)
+    (tmp_path / "notes.txt").write_text("x")
+    assert not is_valid_image_path(str(tmp_path / "notes.txt")) and not is_valid_image_path(str(tmp_path / "missing.png"))
+    with pytest.raises(FileNotFoundError):
+        read_image(str(tmp_path / "missing.png"))
