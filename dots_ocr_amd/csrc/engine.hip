@@ -34,14 +34,17 @@ struct Tensor {
 
 // *_s: per-output-channel fp32 scales of the fp8 configuration (cfg.fp8_weights; quant.hip), nullptr in bf16 mode.  In fp8 mode the
 // row-major matrices hold bf16(q) (exact e4m3 values) and the decode copies (*_wd) hold the e4m3 bytes in fragment order.
+// *_8: the e4m3 bytes row-major — the weight operand of the fp8-MFMA GEMMs (gemm.hip: gemm_fp8_256pp_kernel) of ViT / prefill.
 struct VLayer {
     bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *w13, *b13, *w2, *b2;
     float *qkv_s, *proj_s, *w13_s, *w2_s;
+    uint8_t *qkv_8, *proj_8, *w13_8, *w2_8;
 };
 struct LLayer {
     bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *w13, *down_w;          // row-major [N][K]: prefill GEMMs
     void *qkv_wd, *o_wd, *w13_wd, *down_wd;                          // MFMA fragment order: decode skinny GEMMs
     float *qkv_s, *o_s, *w13_s, *down_s;
+    uint8_t *qkv_8, *o_8, *w13_8, *down_8;
 };
 
 __global__ void pack_w13_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up, bf16_t* __restrict__ out, int I, int K) {
@@ -110,6 +113,10 @@ struct DotsEngine {
     bf16_t *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
     void* lm_head_d = nullptr;
     float *m0_s = nullptr, *m2_s = nullptr, *lm_head_s = nullptr;
+    uint8_t *m0_8 = nullptr, *m2_8 = nullptr;
+    // fp8 mode: per-token quantised activations of the GEMM being launched (max rows x max K bytes) + their scales
+    uint8_t* act_q = nullptr;
+    float* act_s = nullptr;
     std::vector<LLayer> ll;
     float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
 
@@ -253,12 +260,30 @@ void drop(DotsEngine* e, const std::string& name) {
 
 #define RET(x) do { int r_ = (x); if (r_ != DOTS_OK) return r_; } while (0)
 
-// fp8 mode: W <- bf16(q) in place + a fresh scale array; bf16 mode: *scale = nullptr
-int quantize(DotsEngine* e, bf16_t* W, float** scale, int64_t N, int K) {
+// fp8 mode: W <- bf16(q) in place + a fresh scale array + the e4m3 bytes row-major; bf16 mode: *scale = *w8 = nullptr
+int quantize(DotsEngine* e, bf16_t* W, float** scale, int64_t N, int K, uint8_t** w8 = nullptr) {
     *scale = nullptr;
+    if (w8) *w8 = nullptr;
     if (!e->cfg.fp8_weights) return DOTS_OK;
     CK(e->alloc(scale, (size_t)N));
     CK(launch_quant_rows_fp8(e->stream, W, *scale, N, K));
+    if (w8) {
+        if (!gemm_fp8_supports((int)N, K)) return e->fail(DOTS_E_INVALID, "fp8_weights: a %lld x %d linear does not fit the fp8 GEMM (N %% 256, K %% 64)", (long long)N, K);
+        CK(e->alloc(w8, (size_t)N * K));
+        CK(launch_bf16q_to_fp8(e->stream, W, *w8, N * K));
+    }
+    return DOTS_OK;
+}
+
+// One dense layer of ViT / prefill: bf16 MFMA GEMM, or in fp8 mode per-token activation quantisation + the fp8 MFMA GEMM.
+int dense(DotsEngine* e, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale, const bf16_t* bias, const bf16_t* R, void* C,
+          int64_t M, int N, int K, int ldc, int epi) {
+    if (!W8) {
+        CK(launch_gemm(e->stream, A, W, bias, R, C, M, N, K, K, ldc, epi, wscale));
+        return DOTS_OK;
+    }
+    CK(launch_quant_act_fp8(e->stream, A, e->act_q, e->act_s, M, K, K));
+    CK(launch_gemm_fp8(e->stream, e->act_q, e->act_s, W8, wscale, bias, R, C, M, N, K, ldc, epi));
     return DOTS_OK;
 }
 
@@ -323,10 +348,10 @@ int finalize_weights(DotsEngine* e) {
             CK(e->alloc(&L.b13, (size_t)2 * Iv));
             hipLaunchKernelGGL(pack_b13_kernel, dim3((2 * Iv + 255) / 256), dim3(256), 0, s, b1, b3, L.b13, Iv);
         }
-        RET(quantize(e, L.qkv_w, &L.qkv_s, 3 * E, E));
-        RET(quantize(e, L.proj_w, &L.proj_s, E, E));
-        RET(quantize(e, L.w13, &L.w13_s, 2 * Iv, E));          // packed row order: the scale index the SwiGLU epilogue uses
-        RET(quantize(e, L.w2, &L.w2_s, E, Iv));
+        RET(quantize(e, L.qkv_w, &L.qkv_s, 3 * E, E, &L.qkv_8));
+        RET(quantize(e, L.proj_w, &L.proj_s, E, E, &L.proj_8));
+        RET(quantize(e, L.w13, &L.w13_s, 2 * Iv, E, &L.w13_8));          // packed row order: the scale index the SwiGLU epilogue uses
+        RET(quantize(e, L.w2, &L.w2_s, E, Iv, &L.w2_8));
         CK(hipStreamSynchronize(s));
         drop(e, p + "mlp.fc1.weight");
         drop(e, p + "mlp.fc3.weight");
@@ -339,8 +364,8 @@ int finalize_weights(DotsEngine* e) {
     RET(need(e, "vision_tower.merger.mlp.0.bias", {Mg}, &e->m0_b));
     RET(need(e, "vision_tower.merger.mlp.2.weight", {c.hidden_size, Mg}, &e->m2_w));
     RET(need(e, "vision_tower.merger.mlp.2.bias", {c.hidden_size}, &e->m2_b));
-    RET(quantize(e, e->m0_w, &e->m0_s, Mg, Mg));
-    RET(quantize(e, e->m2_w, &e->m2_s, c.hidden_size, Mg));
+    RET(quantize(e, e->m0_w, &e->m0_s, Mg, Mg, &e->m0_8));
+    RET(quantize(e, e->m2_w, &e->m2_s, c.hidden_size, Mg, &e->m2_8));
 
     // ---- language model
     const int H = c.hidden_size, I = c.intermediate_size, Nq = c.num_heads * 128, Nkv = c.num_kv_heads * 128;
@@ -390,10 +415,10 @@ int finalize_weights(DotsEngine* e) {
         }
         CK(e->alloc(&L.w13, (size_t)2 * I * H));
         CK(launch_pack_w13(s, gw, uw, L.w13, I, H));
-        RET(quantize(e, L.qkv_w, &L.qkv_s, Nq + 2 * Nkv, H));
-        RET(quantize(e, L.o_w, &L.o_s, H, Nq));
-        RET(quantize(e, L.w13, &L.w13_s, 2 * I, H));
-        RET(quantize(e, L.down_w, &L.down_s, H, I));
+        RET(quantize(e, L.qkv_w, &L.qkv_s, Nq + 2 * Nkv, H, &L.qkv_8));
+        RET(quantize(e, L.o_w, &L.o_s, H, Nq, &L.o_8));
+        RET(quantize(e, L.w13, &L.w13_s, 2 * I, H, &L.w13_8));
+        RET(quantize(e, L.down_w, &L.down_s, H, I, &L.down_8));
         // decode copies in MFMA fragment order (+3.1 GB of 288 GB, half of that in fp8 mode: every decode weight load is one contiguous chunk)
         RET(decode_copy(e, L.qkv_w, &L.qkv_wd, Nq + 2 * Nkv, H, Nq + Nkv));                   // q / k rows permuted: whole RoPE pairs per tile
         RET(decode_copy(e, L.o_w, &L.o_wd, H, Nq, 0));
@@ -426,6 +451,12 @@ int alloc_workspaces(DotsEngine* e) {
     e->P = c.max_patches;
     e->Ppad = e->P + 64 * 256;                    // every image padded to a multiple of 64 keys
     const int kpad = (int)round_up(c.v_channels * c.v_patch * c.v_patch, 64);
+    if (c.fp8_weights) {
+        const size_t v_max = (size_t)e->P * std::max(E, c.v_intermediate);          // the merger's inputs are [P / g][E g]: P E bytes as well
+        const size_t p_max = (size_t)c.max_prefill_tokens * std::max(H, std::max(Nq, c.intermediate_size));
+        CK(e->alloc(&e->act_q, std::max(v_max, p_max)));
+        CK(e->alloc(&e->act_s, (size_t)std::max<int64_t>(e->P, c.max_prefill_tokens)));
+    }
     CK(e->alloc(&e->v_xa, (size_t)e->P * kpad));
     CK(e->alloc(&e->v_x, (size_t)e->P * E));
     CK(e->alloc(&e->v_xn, (size_t)e->P * E));
@@ -599,16 +630,16 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = e->vl[i];
         CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
-        CK(launch_gemm(s, e->v_xn, L.qkv_w, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, E, 3 * E, EPI_NONE, L.qkv_s));
+        RET(dense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
         CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
         CK(attn_event(e, 2 * i));
         CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale));
         CK(attn_event(e, 2 * i + 1));
         e->attn_pairs = i + 1;
-        CK(launch_gemm(s, e->v_att, L.proj_w, L.proj_b, e->v_x, e->v_x, N, E, E, E, E, EPI_RESIDUAL, L.proj_s));
+        RET(dense(e, e->v_att, L.proj_w, L.proj_8, L.proj_s, L.proj_b, e->v_x, e->v_x, N, E, E, E, EPI_RESIDUAL));
         CK(launch_rmsnorm(s, e->v_x, L.norm2, e->v_xn, N, E, c.v_rms_eps));
-        CK(launch_gemm(s, e->v_xn, L.w13, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, E, c.v_intermediate, EPI_SWIGLU, L.w13_s));
-        CK(launch_gemm(s, e->v_act, L.w2, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, c.v_intermediate, E, EPI_RESIDUAL, L.w2_s));
+        RET(dense(e, e->v_xn, L.w13, L.w13_8, L.w13_s, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, c.v_intermediate, EPI_SWIGLU));
+        RET(dense(e, e->v_act, L.w2, L.w2_8, L.w2_s, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, E, EPI_RESIDUAL));
         if (e->dbg_hidden && (size_t)(i + 1) * N * E <= e->dbg_cap) {
             CK(hipMemcpyAsync(e->dbg_hidden + (size_t)i * N * E, e->v_x, (size_t)N * E * 2, hipMemcpyDeviceToDevice, s));
             e->dbg_vit_rows = N;
@@ -622,8 +653,8 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     CK(launch_layernorm(s, xin, e->m_ln_w, e->m_ln_b, e->v_att, N, E, c.v_ln_eps));
     const int g = m * m, Mg = E * g;
     const int64_t R = N / g;
-    CK(launch_gemm(s, e->v_att, e->m0_w, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, Mg, EPI_GELU, e->m0_s));
-    CK(launch_gemm(s, e->v_mh, e->m2_w, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, Mg, c.hidden_size, EPI_NONE, e->m2_s));
+    RET(dense(e, e->v_att, e->m0_w, e->m0_8, e->m0_s, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, EPI_GELU));
+    RET(dense(e, e->v_mh, e->m2_w, e->m2_8, e->m2_s, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, c.hidden_size, EPI_NONE));
     CK(hipEventRecord(e->ev[1], s));
     e->vis_rows = R;
     if (out_dev) CK(hipMemcpyAsync(out_dev, e->vis, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
@@ -756,14 +787,14 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         const LLayer& Lw = e->ll[i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_rmsnorm(s, e->p_x, Lw.ln1, e->p_xn, T, H, c.rms_norm_eps));
-        CK(launch_gemm(s, e->p_xn, Lw.qkv_w, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, H, NQKV, EPI_NONE, Lw.qkv_s));
+        RET(dense(e, e->p_xn, Lw.qkv_w, Lw.qkv_8, Lw.qkv_s, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, NQKV, EPI_NONE));
         CK(launch_qkv_rope_split(s, e->p_qkv, e->p_cs, e->p_tiles, n_tiles, e->p_q, e->p_k, e->p_vt, T, Tpad, Hq, Hkv));
         CK(launch_kv_to_pages(s, e->p_k, e->p_qkv, e->p_tiles, n_tiles, e->block_table, e->max_pages, pool_l, T, Hq, Hkv));
         CK(launch_flash_attn(s, e->p_q, e->p_k, e->p_vt, e->p_att, e->p_qblocks, (int)e->hp_qblocks.size(), T, Tpad, Hq, Hkv, 1, scale));
-        CK(launch_gemm(s, e->p_att, Lw.o_w, nullptr, e->p_x, e->p_x, T, H, Nq, Nq, H, EPI_RESIDUAL, Lw.o_s));
+        RET(dense(e, e->p_att, Lw.o_w, Lw.o_8, Lw.o_s, nullptr, e->p_x, e->p_x, T, H, Nq, H, EPI_RESIDUAL));
         CK(launch_rmsnorm(s, e->p_x, Lw.ln2, e->p_xn, T, H, c.rms_norm_eps));
-        CK(launch_gemm(s, e->p_xn, Lw.w13, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, H, c.intermediate_size, EPI_SWIGLU, Lw.w13_s));
-        CK(launch_gemm(s, e->p_act, Lw.down_w, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, c.intermediate_size, H, EPI_RESIDUAL, Lw.down_s));
+        RET(dense(e, e->p_xn, Lw.w13, Lw.w13_8, Lw.w13_s, nullptr, nullptr, e->p_act, T, 2 * c.intermediate_size, H, c.intermediate_size, EPI_SWIGLU));
+        RET(dense(e, e->p_act, Lw.down_w, Lw.down_8, Lw.down_s, nullptr, e->p_x, e->p_x, T, H, c.intermediate_size, H, EPI_RESIDUAL));
         const size_t voff = (size_t)c.v_layers * e->dbg_vit_rows * c.v_embed_dim;       // LM layers are stored behind the ViT blocks
         if (e->dbg_hidden && voff + (size_t)(i + 1) * T * H <= e->dbg_cap) {
             CK(hipMemcpyAsync(e->dbg_hidden + voff + (size_t)i * T * H, e->p_x, (size_t)T * H * 2, hipMemcpyDeviceToDevice, s));
@@ -1378,6 +1409,30 @@ int dots_op_gemm(DotsEngine* e, const void* A, const void* W, const void* bias, 
     CK(hipSetDevice(e->device));
     const int ldc = epilogue == EPI_SWIGLU ? N / 2 : N;
     CK(launch_gemm(e->stream, (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)residual, C, M, N, K, K, ldc, epilogue, colscale));
+    return DOTS_OK;
+}
+
+int dots_op_gemm_fp8(DotsEngine* e, const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int N, int K,
+                     int epilogue) {
+    if (!e || !A || !W || !C) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
+    if (!gemm_fp8_supports(N, K) || epilogue == EPI_F32) return e->fail(DOTS_E_INVALID, "fp8 GEMM needs N %% 256 == 0, K %% 64 == 0 and a bf16 output");
+    CK(hipSetDevice(e->device));
+    Scratch sc(e);
+    bf16_t* wq = nullptr;
+    uint8_t *w8 = nullptr, *a8 = nullptr;
+    float *ws = nullptr, *as = nullptr;
+    CK(sc.get(&wq, (size_t)N * K));
+    CK(sc.get(&w8, (size_t)N * K));
+    CK(sc.get(&ws, (size_t)N));
+    CK(sc.get(&a8, (size_t)M * K));
+    CK(sc.get(&as, (size_t)M));
+    CK(hipMemcpyAsync(wq, W, (size_t)N * K * 2, hipMemcpyDeviceToDevice, e->stream));
+    CK(launch_quant_rows_fp8(e->stream, wq, ws, N, K));
+    CK(launch_bf16q_to_fp8(e->stream, wq, w8, (int64_t)N * K));
+    CK(launch_quant_act_fp8(e->stream, (const bf16_t*)A, a8, as, M, K, K));
+    const int ldc = epilogue == EPI_SWIGLU ? N / 2 : N;
+    CK(launch_gemm_fp8(e->stream, a8, as, w8, ws, (const bf16_t*)bias, (const bf16_t*)residual, C, M, N, K, ldc, epilogue));
+    CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
 

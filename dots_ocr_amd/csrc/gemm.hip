@@ -37,11 +37,12 @@ DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
 // nw0 = first weight row (n) of the wave tile, mw0 = first activation row (m) of the wave tile.
 template <int EPI, int FN>
 DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
-                        void* Cout, int M, int ldc, int nw0, int mw0, int l31, int hi) {
+                        void* Cout, int M, int ldc, int nw0, int mw0, int l31, int hi, const float* __restrict__ rowscale = nullptr) {
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm) {
         const int m = mw0 + fm * 32 + l31;
         if (m >= M) continue;
+        const float rs = rowscale ? rowscale[m] : 1.f;           // fp8 activations: per-token scale (quant.hip)
         if constexpr (EPI == EPI_SWIGLU) {
             bf16_t* C = reinterpret_cast<bf16_t*>(Cout);
 #pragma unroll
@@ -53,7 +54,7 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float g = acc[2 * fp][fm][4 * rq + e], u = acc[2 * fp + 1][fm][4 * rq + e];
-                    if (colscale) { g *= colscale[nb + e]; u *= colscale[nb + 32 + e]; }       // fp8 weights: per-output-channel scale (quant.hip)
+                    if (colscale) { g *= colscale[nb + e] * rs; u *= colscale[nb + 32 + e] * rs; }       // fp8 weights: per-output-channel scale (quant.hip)
                     if (bias) { g += bf2f(bias[nb + e]); u += bf2f(bias[nb + 32 + e]); }
                     o[e] = silu(g) * u;
                 }
@@ -73,7 +74,7 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
                     if (colscale) {
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(colscale + nb);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+                        for (int e = 0; e < 4; ++e) o[e] *= sc[e] * rs;
                     }
                     if (bias) {
                         u32x2 bb = *reinterpret_cast<const u32x2*>(bias + nb);
@@ -109,7 +110,7 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
 // executed in order.
 template <int EPI>
 DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
-                            bf16_t* __restrict__ C, int M, int ldc, int nw0, int mw0, int l, char* stage) {
+                            bf16_t* __restrict__ C, int M, int ldc, int nw0, int mw0, int l, char* stage, const float* __restrict__ rowscale = nullptr) {
     const int hi = l >> 5, l31 = l & 31;
     constexpr bool SW = EPI == EPI_SWIGLU;
     // read-side geometry: plain: 4 rows x 16 lanes (8 n each); SwiGLU: 8 rows x 8 lanes (8 outputs each = 8 gate + 8 up inputs)
@@ -142,13 +143,14 @@ DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][2], const bf16_t* __restrict_
             const int s0 = gcol >> 2;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ sw) << 4)), a1 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 1) ^ sw) << 4));
             float o[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const float rs = rowscale ? rowscale[min(m, M - 1)] : 1.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = o[e] * sc0[e] + bi0[e];
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * (sc0[e] * rs) + bi0[e];
             if constexpr (SW) {
                 const f32x4 u0 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 8) ^ sw) << 4)), u1 = *reinterpret_cast<const f32x4*>(rp + (((s0 + 9) ^ sw) << 4));
                 const float u[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = silu(o[e]) * (u[e] * sc1[e] + bi1[e]);
+                for (int e = 0; e < 8; ++e) o[e] = silu(o[e]) * (u[e] * (sc1[e] * rs) + bi1[e]);
             }
             if (m >= M) continue;
             const int col = SW ? nw0 / 2 + ((l & 7) >> 2) * 32 + (l & 3) * 8 : nw0 + gcol;
@@ -507,6 +509,126 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 (e4m3 x e4m3 -> fp32) twin of the ping-pong kernel for the fp8 configuration's ViT / prefill GEMMs (DotsConfig.fp8_weights):
+//     C[m][n] = epilogue( (sum_k Aq[m][k] Wq[n][k]) * rowscale[m] * colscale[n] + bias[n] )
+// Aq = per-token quantised activations (quant.hip: quant_act_fp8), Wq = per-output-channel quantised weights, both row-major bytes.
+// Same byte geometry as the bf16 kernel — a sub-tile row is 64 B, now 64 k instead of 32 — so staging, swizzle, barriers and the
+// epilogues are shared; the 16 bf16 MFMAs of a sub-tile become 8 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (the only
+// K = 64 low-precision MFMA of gfx950; its operand pairing is proven by tests/test_mfma_layout.py): twice the flops per staged byte
+// and per MFMA cycle.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_fp8_256pp_kernel(
+    const uint8_t* __restrict__ A, const float* __restrict__ rowscale, const uint8_t* __restrict__ W, const float* __restrict__ colscale,
+    const bf16_t* __restrict__ bias, const bf16_t* R, void* Cout, int M, int N, int K, int ldc, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    constexpr int SUBK8 = 64;                                   // k per sub-tile (bytes per staged row)
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = l >> 5, l31 = l & 31;
+    const int grp = w >> 2;
+
+    int bid = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int per_group = GROUP_M * n_tiles;
+    const int g = bid / per_group;
+    const int first_m = g * GROUP_M;
+    const int gsz = min(m_tiles - first_m, GROUP_M);
+    const int in_grp = bid - g * per_group;
+    const int tm = first_m + in_grp % gsz;
+    const int tn = in_grp / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    const uint8_t* gw[2];
+    const uint8_t* gx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 8 + w) * 16 + (l >> 2);
+        const int slot = (l & 3) ^ ((l >> 4) & 3);
+        gw[i] = W + (size_t)(n0 + row) * K + slot * 16;
+        gx[i] = A + (size_t)min(m0 + row, M - 1) * K + slot * 16;
+    }
+    auto issue_sub = [&](int p) {
+        char* base = smem2 + (p & (PP_STAGES - 1)) * SUB_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + p * SUBK8),
+                                             (__attribute__((address_space(3))) void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx[i] + p * SUBK8),
+                                             (__attribute__((address_space(3))) void*)(base + SUB_OP + (i * 8 + w) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wn = w >> 2, wm = w & 3;
+    const int rsw = (l31 >> 2) & 3;
+    const int a_off = (wn * 128 + l31) * 64;
+    const int b_off = SUB_OP + (wm * 64 + l31) * 64;
+    const int s_lo = ((2 * hi) ^ rsw) << 4, s_hi = ((2 * hi + 1) ^ rsw) << 4;      // this lane's 32 bytes = logical slots 2hi, 2hi + 1
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ns = K / SUBK8;
+    issue_sub(0);
+    if (ns > 1) issue_sub(1);
+    if (ns > 2) issue_sub(2);
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ns > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto frag = [&](const char* rowp) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(rowp + s_lo), hi4 = *reinterpret_cast<const u32x4*>(rowp + s_hi);
+        const i32x8 v = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        return v;
+    };
+    for (int p = 0; p < ns; ++p) {
+        const char* base = smem2 + (p & (PP_STAGES - 1)) * SUB_STAGE;
+        i32x8 af[4], bf_[2];
+        bf_[0] = frag(base + b_off);
+        bf_[1] = frag(base + b_off + 32 * 64);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) af[fn] = frag(base + a_off + fn * 32 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + PP_LOOKAHEAD < ns) {
+            issue_sub(p + PP_LOOKAHEAD);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            acc[fn][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[fn], bf_[0], acc[fn][0], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc[fn][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[fn], bf_[1], acc[fn][1], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0 || p + 1 < ns) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (EPI == EPI_SWIGLU) {
+        gemm_epilogue<EPI, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 64, l31, hi, rowscale);
+    } else {
+        __syncthreads();
+        gemm_epilogue_lds<EPI>(acc, bias, colscale, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 64, l, smem2 + w * 16384, rowscale);
+    }
+}
+
 }  // namespace
 
 template <int E>
@@ -572,4 +694,38 @@ hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf
     }
 #undef LAUNCH
     return hipGetLastError();
+}
+
+bool gemm_fp8_supports(int N, int K) { return N % BN2 == 0 && K % 64 == 0; }
+
+template <int E>
+static hipError_t launch_fp8_t(hipStream_t s, const uint8_t* Aq, const float* rowscale, const uint8_t* Wq, const float* colscale, const bf16_t* bias,
+                               const bf16_t* R, void* C, int M, int N, int K, int ldc) {
+    static uint32_t configured = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint32_t bit = 1u << (dev & 31);
+    if (!(__atomic_load_n(&configured, __ATOMIC_ACQUIRE) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fp8_256pp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_STAGES * SUB_STAGE);
+        if (e != hipSuccess) return e;
+        __atomic_fetch_or(&configured, bit, __ATOMIC_RELEASE);
+    }
+    const int m_tiles = (M + BM2 - 1) / BM2, n_tiles = N / BN2;
+    hipLaunchKernelGGL(gemm_fp8_256pp_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), PP_STAGES * SUB_STAGE, s, Aq, rowscale, Wq, colscale, bias, R, C, M, N, K,
+                       ldc, m_tiles, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_fp8(hipStream_t s, const uint8_t* Aq, const float* rowscale, const uint8_t* Wq, const float* colscale, const bf16_t* bias,
+                           const bf16_t* R, void* C, int64_t M, int N, int K, int ldc, int epi) {
+    if (M <= 0) return hipSuccess;
+    if (!gemm_fp8_supports(N, K) || ldc % 8 != 0 || !rowscale || !colscale) return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_NONE: return launch_fp8_t<EPI_NONE>(s, Aq, rowscale, Wq, colscale, bias, R, C, (int)M, N, K, ldc);
+        case EPI_RESIDUAL: return launch_fp8_t<EPI_RESIDUAL>(s, Aq, rowscale, Wq, colscale, bias, R, C, (int)M, N, K, ldc);
+        case EPI_SWIGLU: return launch_fp8_t<EPI_SWIGLU>(s, Aq, rowscale, Wq, colscale, bias, R, C, (int)M, N, K, ldc);
+        case EPI_GELU: return launch_fp8_t<EPI_GELU>(s, Aq, rowscale, Wq, colscale, bias, R, C, (int)M, N, K, ldc);
+        default: return hipErrorInvalidValue;
+    }
 }

@@ -86,6 +86,14 @@ hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows
 hipError_t launch_quant_rows_fp8(hipStream_t s, bf16_t* W, float* scale, int64_t N, int K);
 // bf16(q) row-major [rows, K] -> e4m3 bytes in decode fragment order (512-B chunks); rot_rows = (Hq + Hkv) * 128 for the fused qkv weight, else 0
 hipError_t launch_pack_frag_fp8(hipStream_t s, const bf16_t* src, uint8_t* dst, int64_t rows, int K, int rot_rows);
+// activations: x bf16 [M][lda] -> q e4m3 [M][K] + scale[m] (per token); bf16(q) weights -> e4m3 bytes row-major
+hipError_t launch_quant_act_fp8(hipStream_t s, const bf16_t* X, uint8_t* Q, float* scale, int64_t M, int K, int lda);
+hipError_t launch_bf16q_to_fp8(hipStream_t s, const bf16_t* src, uint8_t* dst, int64_t n);
+// ---- gemm.hip, fp8 MFMA: C = epilogue((Aq Wq^T) * rowscale[m] * colscale[n] + bias); Aq [M][K], Wq [N][K] e4m3 row-major;
+// N % 256 == 0, K % 64 == 0, ldc % 8 == 0.  EPI_F32 is not offered.
+hipError_t launch_gemm_fp8(hipStream_t s, const uint8_t* Aq, const float* rowscale, const uint8_t* Wq, const float* colscale, const bf16_t* bias,
+                           const bf16_t* R, void* C, int64_t M, int N, int K, int ldc, int epi);
+bool gemm_fp8_supports(int N, int K);
 // ---- engine.hip helper kernels
 hipError_t launch_pack_w13(hipStream_t s, const bf16_t* gate, const bf16_t* up, bf16_t* out, int I, int K);
 hipError_t launch_convert_to_bf16(hipStream_t s, const void* src, int dtype, bf16_t* dst, int64_t n);

@@ -41,6 +41,25 @@ __global__ void probe_mfma_16x16x32(const uint16_t* A, const uint16_t* Bt, float
     for (int r = 0; r < 4; ++r) D[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
 }
 
+// fp8 (OCP e4m3) on the block-scaled instruction with unit scales (E8M0 0x7f = 2^0), the only K = 64 low-precision MFMA of gfx950:
+//   v_mfma_scale_f32_32x32x64_f8f6f4 : lane l supplies 32 bytes of A row i = l & 31 and of B column j = l & 31, both the SAME 32
+//   contraction positions k = 32*(l>>5) + [0, 32) in the same byte order; D as the bf16 32x32 shape.  Only the A <-> B pairing
+//   of byte positions matters for a GEMM (a dot product is order-free), and that is what the test proves.
+// A: [32][64] e4m3 row-major, Bt: [32][64] e4m3 (row j = B[:, j]), D: [32][32] f32
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__global__ void probe_mfma_32x32x64_fp8(const uint8_t* A, const uint8_t* Bt, float* D) {
+    const int l = threadIdx.x;
+    i32x8 a = *reinterpret_cast<const i32x8*>(A + (l & 31) * 64 + 32 * (l >> 5));
+    i32x8 b = *reinterpret_cast<const i32x8*>(Bt + (l & 31) * 64 + 32 * (l >> 5));
+    f32x16 c = {0};
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        D[row * 32 + (l & 31)] = c[r];
+    }
+}
+
 // LDS-DMA probe: each lane copies 16 B global -> LDS (wave-uniform base + lane*16), then
 // the wave writes the LDS image back out.  out[i] must equal in[i] for 256 dwords.
 __global__ void probe_glds(const uint32_t* in, uint32_t* out) {
@@ -59,6 +78,7 @@ extern "C" int dots_probe_mfma(int which, const void* A, const void* Bt, void* D
     hipStream_t s = (hipStream_t)stream;
     if (which == 0) hipLaunchKernelGGL(probe_mfma_32x32x16, dim3(1), dim3(64), 0, s, (const uint16_t*)A, (const uint16_t*)Bt, (float*)D);
     else if (which == 1) hipLaunchKernelGGL(probe_mfma_16x16x32, dim3(1), dim3(64), 0, s, (const uint16_t*)A, (const uint16_t*)Bt, (float*)D);
+    else if (which == 3) hipLaunchKernelGGL(probe_mfma_32x32x64_fp8, dim3(1), dim3(64), 0, s, (const uint8_t*)A, (const uint8_t*)Bt, (float*)D);
     else hipLaunchKernelGGL(probe_glds, dim3(1), dim3(64), 0, s, (const uint32_t*)A, (uint32_t*)D);
     return (int)hipGetLastError();
 }

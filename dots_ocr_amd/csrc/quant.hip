@@ -73,7 +73,64 @@ __global__ __launch_bounds__(256) void pack_frag_fp8_kernel(const bf16_t* __rest
     *reinterpret_cast<u32x2*>(dst + (t * 64 + fp8_lane_slot(g, i)) * 8) = o;
 }
 
+// Dynamic per-token activation quantisation for the fp8-MFMA GEMMs (gemm.hip: gemm_fp8_256pp_kernel): x bf16 [M][lda] ->
+// q e4m3 [M][K] row-major + scale[m] = max|x[m][:]| / 448 (1 for a zero row): the same definition as the weights' (per row).
+__global__ __launch_bounds__(256) void quant_act_fp8_kernel(const bf16_t* __restrict__ X, uint8_t* __restrict__ Q, float* __restrict__ scale,
+                                                            int64_t M, int K, int lda) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bf16_t* row = X + m * lda;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(lo_bf(v[e])), fabsf(hi_bf(v[e]))));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) scale[m] = sc;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + k);
+        u32x2 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int p = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * h]) / sc, hi_bf(v[2 * h]) / sc, 0, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * h + 1]) / sc, hi_bf(v[2 * h + 1]) / sc, p, true);
+            o[h] = (uint32_t)p;
+        }
+        *reinterpret_cast<u32x2*>(Q + m * K + k) = o;
+    }
+}
+
+// bf16(q) row-major [N][K] (exact e4m3 values, launch_quant_rows_fp8) -> the e4m3 bytes, row-major: the fp8 GEMM's weight operand
+__global__ __launch_bounds__(256) void bf16q_to_fp8_kernel(const bf16_t* __restrict__ src, uint8_t* __restrict__ dst, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 8);
+    u32x2 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int p = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * h]), hi_bf(v[2 * h]), 0, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(lo_bf(v[2 * h + 1]), hi_bf(v[2 * h + 1]), p, true);
+        o[h] = (uint32_t)p;
+    }
+    *reinterpret_cast<u32x2*>(dst + i * 8) = o;
+}
+
 }  // namespace
+
+hipError_t launch_quant_act_fp8(hipStream_t s, const bf16_t* X, uint8_t* Q, float* scale, int64_t M, int K, int lda) {
+    if (K % 8 != 0 || lda % 8 != 0 || M < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quant_act_fp8_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, X, Q, scale, M, K, lda);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16q_to_fp8(hipStream_t s, const bf16_t* src, uint8_t* dst, int64_t n) {
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bf16q_to_fp8_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, src, dst, n / 8);
+    return hipGetLastError();
+}
 
 hipError_t launch_quant_rows_fp8(hipStream_t s, bf16_t* W, float* scale, int64_t N, int K) {
     if (K % 8 != 0 || N < 1) return hipErrorInvalidValue;

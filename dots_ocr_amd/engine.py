@@ -92,6 +92,7 @@ def _prototypes(lib):
         "dots_op_layernorm": (i32, [vp, vp, vp, vp, vp, i64, i32, f32]),
         "dots_op_gemm": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
         "dots_op_quant_fp8": (i32, [vp, vp, vp, i64, i32]),
+        "dots_op_gemm_fp8": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]),
         "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
         "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
         "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32]),
@@ -116,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
-    "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8",
+    "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8", "dots_op_gemm_fp8",
     "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
     "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
@@ -399,6 +400,9 @@ class Engine:
 
     def op_gemm(self, A, W, bias, residual, Cout, M, N, K, epilogue=EPI_NONE, colscale=None):
         self._ck(self.lib.dots_op_gemm(self.h, A, W, bias or None, residual or None, Cout, M, N, K, epilogue, colscale or None), "dots_op_gemm")
+
+    def op_gemm_fp8(self, A, W, bias, residual, Cout, M, N, K, epilogue=EPI_NONE):
+        self._ck(self.lib.dots_op_gemm_fp8(self.h, A, W, bias or None, residual or None, Cout, M, N, K, epilogue), "dots_op_gemm_fp8")
 
     def op_quant_fp8(self, w_inout, scale_out, N, K):
         self._ck(self.lib.dots_op_quant_fp8(self.h, w_inout, scale_out, N, K), "dots_op_quant_fp8")

@@ -60,8 +60,10 @@ typedef struct DotsConfig {
                                  prompt + generation cap when it is prefilled.  0 = max_batch * max_seq_len (never refuses) */
     int32_t fp8_weights;      /* != 0: dots_finalize_weights quantises every ViT-block / merger / LM linear and the lm_head to OCP e4m3 with
                                  one fp32 scale per output channel (scale = max|row| / 448; csrc/quant.hip).  The decode step streams
-                                 the e4m3 bytes (half the HBM traffic); ViT / prefill GEMMs multiply the same quantised values on the
-                                 bf16 MFMA.  Embedding table, patch embedding, norms and biases stay bf16.  (BASELINE configs[4]) */
+                                 the e4m3 bytes (half the HBM traffic) against bf16 activations; the ViT / prefill GEMMs quantise
+                                 their input activations per token the same way and run on the fp8 MFMA (W8A8).  Every quantised
+                                 linear needs N % 256 == 0 and K % 64 == 0.  Embedding table, patch embedding, norms and biases
+                                 stay bf16.  (BASELINE configs[4]) */
     int32_t _reserved;
 } DotsConfig;
 
@@ -196,6 +198,10 @@ int dots_op_gemm(DotsEngine* e, const void* A_dev, const void* W_dev, const void
  * fp8 weights; W then holds the quantised values).
  * dots_op_quant_fp8: W bf16 [N,K] -> bf16(e4m3(W[n][:] / scale[n])) in place, scale_out[n] = max|W[n][:]| / 448 (1 for a zero row). */
 int dots_op_quant_fp8(DotsEngine* e, void* w_inout_dev, float* scale_out_dev, int64_t N, int K);
+/* The ViT / prefill GEMM of an fp8_weights engine: A bf16 [M,K] is quantised per token and W bf16 [N,K] per output channel to e4m3
+ * (copies), then C = epilogue((Aq Wq^T) * a_scale[m] * w_scale[n] + bias) on the fp8 MFMA.  N % 256 == 0, K % 64 == 0; epilogues 0-3. */
+int dots_op_gemm_fp8(DotsEngine* e, const void* A_dev, const void* W_dev, const void* bias_dev, const void* residual_dev, void* C_dev,
+                     int64_t M, int N, int K, int epilogue);
 /* Flash attention over packed sequences.  q [Hq, T, 128], k [Hkv, T, 128] bf16 (head-major),
  * vt [Hkv, 128, Tpad] (V transposed, every sequence padded to 64 keys, keys permuted inside
  * 16-groups as csrc/attn_prefill.hip documents), cu_seqlens int32 [n_seq+1] (host).

@@ -63,7 +63,11 @@ def rotate_half(x: torch.Tensor) -> torch.Tensor:
     return torch.cat((-x2, x1), dim=-1)
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, a8: bool = False) -> torch.Tensor:
+    """a8: the input activations are quantised per row (token) to e4m3 first — what the fp8 engine's ViT / prefill GEMMs do."""
+    if a8:
+        q, s = quantize_rows_fp8(x)
+        x = q * s[:, None]
     y = x @ w.t()
     return y if b is None else y + b
 
@@ -89,8 +93,9 @@ FP8_LINEAR_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", 
 def quantize_fp8_state_dict(sd: SD) -> SD:
     """The state dict an fp8_weights engine computes with: every ViT-block / merger / LM linear and the lm_head (a copy of the
     embedding table when tied) replaced by q * scale in fp32; embeddings, the patch embedding, norms and biases untouched.
-    Running the oracle on it IS the fp8 oracle mode: y = x @ (q * scale)^T differs from the engine's (x @ q^T) * scale by fp32
-    rounding only, and the bf16 storage points of emulate_bf16 are the same as in the bf16 configuration."""
+    The fp8 oracle mode = the oracle on this state dict with generate(..., fp8_act=True) (per-token e4m3 activations into the
+    ViT / prefill linears, as the engine's fp8-MFMA GEMMs get them): y = (qa sa) @ (qw sw)^T differs from the engine's
+    (qa @ qw^T) sa sw by fp32 rounding only, and the bf16 storage points of emulate_bf16 are those of the bf16 configuration."""
     out = dict(sd)
     if "lm_head.weight" not in out:
         out["lm_head.weight"] = sd["model.embed_tokens.weight"]
@@ -147,7 +152,7 @@ def _attention(q, k, v, scale: float, causal: bool, emu: bool, q_chunk: int = 20
 
 
 def vision_block(sd: SD, p: str, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, seqlens, n_heads: int, head_dim: int,
-                 eps: float, emu: bool) -> torch.Tensor:
+                 eps: float, emu: bool, a8: bool = False) -> torch.Tensor:
     """One pre-norm transformer block of the vision tower on packed patches x [N, E] (cos/sin [N, 1, head_dim]):
          x += proj(attention(rope(qkv(rmsnorm1(x)))))      bidirectional, one sequence per image
          x += fc2(silu(fc1(rmsnorm2(x))) * fc3(rmsnorm2(x)))
@@ -157,7 +162,7 @@ def vision_block(sd: SD, p: str, x: torch.Tensor, cos: torch.Tensor, sin: torch.
     scale = 1.0 / math.sqrt(head_dim)
     h = rms_norm(x, _w(sd, p + "norm1.weight"), eps, emu)
     qb = sd.get(p + "attn.qkv.bias")
-    qkv = _r(linear(h, _w(sd, p + "attn.qkv.weight"), None if qb is None else qb.float()), emu)
+    qkv = _r(linear(h, _w(sd, p + "attn.qkv.weight"), None if qb is None else qb.float(), a8), emu)
     q, k, vv = qkv.view(-1, 3, n_heads, head_dim).unbind(1)    # [N,H,D]
     q = _r(q * cos + rotate_half(q) * sin, emu)
     k = _r(k * cos + rotate_half(k) * sin, emu)
@@ -168,18 +173,19 @@ def vision_block(sd: SD, p: str, x: torch.Tensor, cos: torch.Tensor, sin: torch.
                                     vv[s0:s0 + n].transpose(0, 1), scale, False, emu).transpose(0, 1)
         s0 += n
     pb = sd.get(p + "attn.proj.bias")
-    x = _r(x + linear(att.reshape(-1, E), _w(sd, p + "attn.proj.weight"), None if pb is None else pb.float()), emu)
+    x = _r(x + linear(att.reshape(-1, E), _w(sd, p + "attn.proj.weight"), None if pb is None else pb.float(), a8), emu)
     h = rms_norm(x, _w(sd, p + "norm2.weight"), eps, emu)
     b1, b2, b3 = (sd.get(p + f"mlp.fc{j}.bias") for j in (1, 2, 3))
-    g = linear(h, _w(sd, p + "mlp.fc1.weight"), None if b1 is None else b1.float())
-    u = linear(h, _w(sd, p + "mlp.fc3.weight"), None if b3 is None else b3.float())
+    g = linear(h, _w(sd, p + "mlp.fc1.weight"), None if b1 is None else b1.float(), a8)
+    u = linear(h, _w(sd, p + "mlp.fc3.weight"), None if b3 is None else b3.float(), a8)
     a = _r(F.silu(g) * u, emu)                     # fused epilogue: one rounding
-    return _r(x + linear(a, _w(sd, p + "mlp.fc2.weight"), None if b2 is None else b2.float()), emu)
+    return _r(x + linear(a, _w(sd, p + "mlp.fc2.weight"), None if b2 is None else b2.float(), a8), emu)
 
 
 def vision_tower(sd: SD, cfg, pixel_values: torch.Tensor, grid_thw: torch.Tensor,
-                 emulate_bf16: bool = False, return_hidden: bool = False):
-    """pixel_values [N, C*T*P*P] f32, grid_thw [n_img, 3] -> merged embeddings [N/merge^2, hidden]."""
+                 emulate_bf16: bool = False, return_hidden: bool = False, a8: bool = False):
+    """pixel_values [N, C*T*P*P] f32, grid_thw [n_img, 3] -> merged embeddings [N/merge^2, hidden].
+    a8: per-token e4m3 activations into every block / merger linear (the patch embedding stays unquantised)."""
     v = cfg.vision
     emu = emulate_bf16
     E, Hh, D = v.embed_dim, v.num_attention_heads, v.head_dim
@@ -198,7 +204,7 @@ def vision_tower(sd: SD, cfg, pixel_values: torch.Tensor, grid_thw: torch.Tensor
     scale = 1.0 / math.sqrt(D)
     hiddens = []
     for i in range(v.num_hidden_layers):
-        x = vision_block(sd, f"{pre}blocks.{i}.", x, cos, sin, seqlens, Hh, D, v.rms_norm_eps, emu)
+        x = vision_block(sd, f"{pre}blocks.{i}.", x, cos, sin, seqlens, Hh, D, v.rms_norm_eps, emu, a8)
         if return_hidden:
             hiddens.append(x.clone())
     if v.post_norm:
@@ -206,8 +212,8 @@ def vision_tower(sd: SD, cfg, pixel_values: torch.Tensor, grid_thw: torch.Tensor
     # PatchMerger (cf. modeling_qwen2_vl.py:277-290)
     x = layer_norm(x, _w(sd, pre + "merger.ln_q.weight"), _w(sd, pre + "merger.ln_q.bias"), v.merger_ln_eps, emu)
     x = x.view(-1, E * v.spatial_merge_size ** 2)
-    x = _r(F.gelu(linear(x, _w(sd, pre + "merger.mlp.0.weight"), _w(sd, pre + "merger.mlp.0.bias"))), emu)
-    x = _r(linear(x, _w(sd, pre + "merger.mlp.2.weight"), _w(sd, pre + "merger.mlp.2.bias")), emu)
+    x = _r(F.gelu(linear(x, _w(sd, pre + "merger.mlp.0.weight"), _w(sd, pre + "merger.mlp.0.bias"), a8)), emu)
+    x = _r(linear(x, _w(sd, pre + "merger.mlp.2.weight"), _w(sd, pre + "merger.mlp.2.bias"), a8), emu)
     return (x, hiddens) if return_hidden else x
 
 
@@ -235,8 +241,10 @@ class KVCache:
 
 
 def lm_forward(sd: SD, cfg, embeds: torch.Tensor, cache: KVCache, emulate_bf16: bool = False,
-               last_only: bool = True, return_hidden: bool = False):
-    """One sequence. embeds [T, hidden]; appends to cache; returns fp32 logits [1 or T, vocab]."""
+               last_only: bool = True, return_hidden: bool = False, a8: bool = False):
+    """One sequence. embeds [T, hidden]; appends to cache; returns fp32 logits [1 or T, vocab].
+    a8: per-token e4m3 activations into the seven layer linears (the fp8 engine's PREFILL; its decode step and the lm_head keep
+    bf16 activations)."""
     emu = emulate_bf16
     T = embeds.shape[0]
     Hq, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -250,19 +258,19 @@ def lm_forward(sd: SD, cfg, embeds: torch.Tensor, cache: KVCache, emulate_bf16: 
         p = f"model.layers.{i}."
         h = rms_norm(x, _w(sd, p + "input_layernorm.weight"), cfg.rms_norm_eps, emu)
         bq, bk, bv = (sd.get(p + f"self_attn.{n}_proj.bias") for n in "qkv")
-        q = _r(linear(h, _w(sd, p + "self_attn.q_proj.weight"), None if bq is None else bq.float()), emu).view(T, Hq, D)
-        k = _r(linear(h, _w(sd, p + "self_attn.k_proj.weight"), None if bk is None else bk.float()), emu).view(T, Hkv, D)
-        vv = _r(linear(h, _w(sd, p + "self_attn.v_proj.weight"), None if bv is None else bv.float()), emu).view(T, Hkv, D)
+        q = _r(linear(h, _w(sd, p + "self_attn.q_proj.weight"), None if bq is None else bq.float(), a8), emu).view(T, Hq, D)
+        k = _r(linear(h, _w(sd, p + "self_attn.k_proj.weight"), None if bk is None else bk.float(), a8), emu).view(T, Hkv, D)
+        vv = _r(linear(h, _w(sd, p + "self_attn.v_proj.weight"), None if bv is None else bv.float(), a8), emu).view(T, Hkv, D)
         q = _r(q * cos + rotate_half(q) * sin, emu)
         k = _r(k * cos + rotate_half(k) * sin, emu)
         K, V = cache.append(i, k.transpose(0, 1), vv.transpose(0, 1))      # [Hkv, ctx, D]
         rep = Hq // Hkv
         att = _attention(q.transpose(0, 1), K.repeat_interleave(rep, dim=0), V.repeat_interleave(rep, dim=0),
                          scale, True, emu).transpose(0, 1).reshape(T, Hq * D)
-        x = _r(x + linear(att, _w(sd, p + "self_attn.o_proj.weight")), emu)
+        x = _r(x + linear(att, _w(sd, p + "self_attn.o_proj.weight"), None, a8), emu)
         h = rms_norm(x, _w(sd, p + "post_attention_layernorm.weight"), cfg.rms_norm_eps, emu)
-        a = _r(F.silu(linear(h, _w(sd, p + "mlp.gate_proj.weight"))) * linear(h, _w(sd, p + "mlp.up_proj.weight")), emu)
-        x = _r(x + linear(a, _w(sd, p + "mlp.down_proj.weight")), emu)
+        a = _r(F.silu(linear(h, _w(sd, p + "mlp.gate_proj.weight"), None, a8)) * linear(h, _w(sd, p + "mlp.up_proj.weight"), None, a8), emu)
+        x = _r(x + linear(a, _w(sd, p + "mlp.down_proj.weight"), None, a8), emu)
         if return_hidden:
             hiddens.append(x.clone())
     if last_only:
@@ -288,20 +296,22 @@ def build_embeds(sd: SD, cfg, input_ids: torch.Tensor, vision_embeds: Optional[t
 def generate(sd: SD, cfg, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
              grid_thw: Optional[torch.Tensor], max_new_tokens: int, eos_ids: Tuple[int, ...] = (),
              emulate_bf16: bool = False, forced_tokens: Optional[List[int]] = None,
-             return_logits: bool = False, vision_embeds: Optional[torch.Tensor] = None):
+             return_logits: bool = False, vision_embeds: Optional[torch.Tensor] = None, fp8_act: bool = False):
     """Greedy decode of ONE sequence (reference parser.py:110 with do_sample=False).
     forced_tokens: teacher forcing (feed these instead of the argmax) so per-step logits can be
     compared with an engine that took a different branch at a near-tie.
     vision_embeds: merged vision rows computed elsewhere (skips the tower: LM-only comparisons at full context length).
+    fp8_act: the fp8 engine's W8A8 phases — vision tower and PREFILL quantise the inputs of their linears per token; decode steps do
+             not (weight-only there).  Use together with quantize_fp8_state_dict(sd).
     Returns (new_token_ids, [logits per step] if return_logits)."""
     vis = vision_embeds
     if vis is None and pixel_values is not None:
-        vis = vision_tower(sd, cfg, pixel_values, grid_thw, emulate_bf16)
+        vis = vision_tower(sd, cfg, pixel_values, grid_thw, emulate_bf16, a8=fp8_act)
     emb = build_embeds(sd, cfg, input_ids, vis)
     if emulate_bf16:
         emb = _r(emb, True)
     cache = KVCache(cfg.num_hidden_layers)
-    logits = lm_forward(sd, cfg, emb, cache, emulate_bf16)
+    logits = lm_forward(sd, cfg, emb, cache, emulate_bf16, a8=fp8_act)
     out, all_logits = [], []
     for step in range(max_new_tokens):
         if return_logits:

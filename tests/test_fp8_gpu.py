@@ -1,11 +1,13 @@
-"""fp8-weight configuration (BASELINE configs[4]; DotsConfig.fp8_weights, csrc/quant.hip): OCP e4m3 weights with one fp32 scale
-per output channel, streamed as bytes by the decode kernels and multiplied as bf16(q) by the ViT / prefill GEMMs.
+"""fp8 configuration (BASELINE configs[4]; DotsConfig.fp8_weights, csrc/quant.hip): OCP e4m3 weights with one fp32 scale per output
+channel — streamed as bytes against bf16 activations by the decode kernels (W8A16), multiplied with per-token e4m3 activations on
+the fp8 MFMA by the ViT / prefill GEMMs (W8A8, gemm.hip: gemm_fp8_256pp_kernel).
 
   * the quantiser equals torch's float8_e4m3fn cast bit for bit (values and scales), zero rows and tiny rows included;
   * every decode kernel's fp8 instantiation, at the BASELINE dimensions, equals the oracle run on the quantised weights
     (oracle/model.py quantize_rows_fp8: the "fp8 oracle mode") to the same tolerances as the bf16 kernels;
-  * the GEMM's per-column scale epilogue equals the oracle on the quantised weights;
-  * a whole fp8 engine (ViT -> prefill -> decode) follows the oracle on the quantised state dict, and decode continues prefill.
+  * the fp8-MFMA GEMM (activation quantiser + kernel + row/column-scale epilogues) equals the oracle's a8 linear; the bf16 GEMM's
+    per-column scale epilogue equals the oracle on the quantised weights;
+  * a whole fp8 engine (ViT -> prefill -> decode) follows the oracle's fp8 mode (quantize_fp8_state_dict + fp8_act=True).
 """
 import numpy as np
 import pytest
@@ -202,11 +204,54 @@ def test_gemm_column_scale_epilogue(eng, epi):
     close(Cd, ref, rel=2 ** -7, abs_=2e-3, what=epi)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (1000, 768, 192), (4100, 1536, 1536), (515, 512, 4224)])
+@pytest.mark.parametrize("epi", ["none", "residual", "gelu"])
+def test_fp8_mfma_gemm_equals_the_oracle_a8_linear(eng, M, N, K, epi):
+    from dots_ocr_amd.engine import EPI_GELU, EPI_NONE, EPI_RESIDUAL
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M).view(-1, 1))                # per-token scales over 3 decades
+    A[3] = 0                                                                                       # an all-zero token
+    W = bf(torch.randn(N, K, generator=g) / K ** 0.5 * torch.logspace(-1, 1, N).view(-1, 1))
+    bias = bf(torch.randn(N, generator=g) * 0.1)
+    R = bf(torch.randn(M, N, generator=g))
+    Ad, Wd_, bd, Rd = dev(A), dev(W), dev(bias), dev(R)
+    Cd = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    code = {"none": EPI_NONE, "residual": EPI_RESIDUAL, "gelu": EPI_GELU}[epi]
+    eng.op_gemm_fp8(Ad.data_ptr(), Wd_.data_ptr(), bd.data_ptr(), Rd.data_ptr() if epi == "residual" else None, Cd.data_ptr(), M, N, K, code)
+    y = om.linear(A.float(), dq(W), bias.float(), a8=True)
+    if epi == "residual":
+        y = y + R.float()
+    if epi == "gelu":
+        y = torch.nn.functional.gelu(y)
+    close(Cd, om._r(y, True), rel=2 ** -7, abs_=2e-3, what=f"fp8 gemm {epi}")
+    assert torch.equal(Ad.cpu(), A) and torch.equal(Wd_.cpu(), W), "the op quantises copies"
+
+
+def test_fp8_mfma_gemm_swiglu_and_repeatability(eng):
+    from dots_ocr_amd.engine import EPI_SWIGLU
+    g = torch.Generator().manual_seed(77)
+    M, I, K = 3000, 1024, 1536
+    A = bf(torch.randn(M, K, generator=g))
+    Wg, Wu = bf(torch.randn(I, K, generator=g) / K ** 0.5), bf(torch.randn(I, K, generator=g) / K ** 0.5 * 2)
+    W13 = torch.stack([Wg.view(I // 32, 32, K), Wu.view(I // 32, 32, K)], dim=1).reshape(2 * I, K).contiguous()
+    Ad, Wd_ = dev(A), dev(W13)
+    outs = []
+    for _ in range(4):
+        Cd = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
+        eng.op_gemm_fp8(Ad.data_ptr(), Wd_.data_ptr(), None, None, Cd.data_ptr(), M, 2 * I, K, EPI_SWIGLU)
+        outs.append(Cd.cpu())
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16)), "fp8 GEMM result changes between runs"
+    ref = om._r(torch.nn.functional.silu(om.linear(A.float(), dq(Wg), None, a8=True)) * om.linear(A.float(), dq(Wu), None, a8=True), True)
+    close(outs[0], ref, rel=2 ** -6, abs_=2e-3, what="fp8 swiglu")
+
+
 # ------------------------------------------------------------------------------------------------ whole engine
 def test_fp8_engine_follows_the_oracle_on_the_quantised_state_dict():
-    """Small dimensions, both phases: ViT + prefill (bf16(q) GEMMs with the scale epilogue) and 12 decode steps (e4m3 byte
-    stream), greedy, teacher-forced oracle on quantize_fp8_state_dict(sd).  The fp8 model is NOT the bf16 model: the same
-    prompt through a bf16 engine must give different logits."""
+    """Small dimensions, both phases: ViT + prefill (per-token e4m3 activations x e4m3 weights on the fp8 MFMA) and 12 decode steps
+    (e4m3 byte stream x bf16 activations), greedy, teacher-forced oracle on quantize_fp8_state_dict(sd) with fp8_act=True.  The
+    fp8 model is NOT the bf16 model: the same prompt through a bf16 engine must give different logits."""
     from dots_ocr_amd.config import DotsConfig
     from dots_ocr_amd.engine import Engine
     from dots_ocr_amd.image_utils import preprocess_image
@@ -233,17 +278,22 @@ def test_fp8_engine_follows_the_oracle_on_the_quantised_state_dict():
     lg, tk = out[True]
     qsd = om.quantize_fp8_state_dict(sd)
     _, ref = om.generate(qsd, cfg, torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(pv), torch.tensor([thw]), n_new,
-                         emulate_bf16=True, forced_tokens=tk, return_logits=True)
+                         emulate_bf16=True, forced_tokens=tk, return_logits=True, fp8_act=True)
     _, ref32 = om.generate(qsd, cfg, torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(pv), torch.tensor([thw]), n_new,
-                           emulate_bf16=False, forced_tokens=tk, return_logits=True)
-    worst = 0.0
+                           emulate_bf16=False, forced_tokens=tk, return_logits=True, fp8_act=True)
+    # Tolerances: per-token activation quantisation is a step function — a bf16-level difference between two computations of the same
+    # activation can flip an e4m3 rounding (6 % of that element), so W8A8 logits scatter more around the oracle than the bf16
+    # configuration's (3 % of the logit range there): 4 % vs the emulated oracle, 6 % vs the fp32 one.
+    worst, worst_emu = 0.0, 0.0
     for s in range(n_new):
         got = torch.from_numpy(lg[s])
         rng = float(ref32[s].max() - ref32[s].min())
         worst = max(worst, float((got - ref32[s]).abs().max()) / rng)
+        worst_emu = max(worst_emu, float((got - ref[s]).abs().max()) / rng)
         best = int(ref[s].argmax())
-        assert tk[s] == best or float(ref[s][best] - ref[s][tk[s]]) < 0.03 * rng, f"step {s}: token {tk[s]} vs fp8 oracle {best}"
-    assert worst < 0.02, f"max |logit err| vs the fp32 fp8-oracle = {worst:.4f} of the logit range"
+        assert tk[s] == best or float(ref[s][best] - ref[s][tk[s]]) < 0.05 * rng, f"step {s}: token {tk[s]} vs fp8 oracle {best}"
+    print(f"fp8 engine: max |logit err| {worst_emu:.4f} (emulated oracle) / {worst:.4f} (fp32 oracle) of the logit range")
+    assert worst_emu < 0.04 and worst < 0.06, f"max |logit err| = {worst_emu:.4f} (emulated) / {worst:.4f} (fp32) of the logit range"
     # and the quantisation is really in effect
     d = max(float(np.abs(a - b).max()) for a, b in zip(out[True][0], out[False][0]))
     assert d > 1e-2, "fp8 and bf16 engines produced the same logits"

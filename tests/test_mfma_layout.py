@@ -33,6 +33,28 @@ def test_mfma_maps(which, m, k):
     assert (D.cpu() - ref.t()).abs().max().item() > 1e-2      # the check is transpose-detecting
 
 
+def test_mfma_fp8_32x32x64_pairs_equal_byte_positions():
+    """v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands and unit scales: lane l feeds bytes [32 (l >> 5), +32) of row l & 31 for
+    A and for B -> D = A B^T.  The block-scaled datapath does not keep every bit of a 64-term sum (measured 2.5e-3 on sums of
+    magnitude ~30, i.e. ~1e-4 relative, against ~1e-7 for fp32 accumulation): the tolerance allows that, a wrong pairing is O(10)."""
+    import torch
+    from dots_ocr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(31)
+    A = (torch.randn(32, 64, generator=g) * 2).to(torch.float8_e4m3fn)
+    Bt = (torch.randn(32, 64, generator=g) * 2).to(torch.float8_e4m3fn)
+    ref = A.float() @ Bt.float().t()
+    Ad, Bd = A.cuda(), Bt.cuda()
+    D = torch.zeros(32, 32, dtype=torch.float32, device="cuda")
+    rc = lib.dots_probe_mfma(3, ctypes.c_void_p(Ad.data_ptr()), ctypes.c_void_p(Bd.data_ptr()),
+                             ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (D.cpu() - ref).abs().max().item()
+    assert err < 2e-2, f"fp8 MFMA map mismatch: max err {err}"
+    assert (D.cpu() - ref.t()).abs().max().item() > 1.0
+
+
 def test_lds_dma():
     import torch
     from dots_ocr_amd import _lib
