@@ -46,7 +46,7 @@ def run(eng, fn, *a):
     eng.synchronize()
 
 
-@pytest.mark.parametrize("rows,dim", [(1, 256), (37, 768), (513, 1536), (5, 4096)])
+@pytest.mark.parametrize("rows,dim", [(1, 256), (37, 768), (513, 1536), (5, 4096), (9, 512), (66, 1024)])
 def test_rmsnorm(eng, rows, dim):
     g = torch.Generator().manual_seed(rows)
     x = bf(torch.randn(rows, dim, generator=g) * 3)
