@@ -1217,16 +1217,20 @@ int dots_get_stats(DotsEngine* e, DotsStats* out) {
     if (!e || !out) return DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     CK(hipStreamSynchronize(e->stream));
-    auto el = [&](int a, int b) { float ms = 0; if (hipEventElapsedTime(&ms, e->ev[a], e->ev[b]) != hipSuccess) ms = 0; return ms; };
+    // An event pair that was never recorded (e.g. the static-batch events after a slot-mode run) makes hipEventElapsedTime fail; the
+    // failure must not stay behind as the thread's "last error" (PyTorch / RCCL check hipGetLastError after their own launches).
+    auto elapsed = [&](hipEvent_t a, hipEvent_t b) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
+        return ms;
+    };
+    auto el = [&](int a, int b) { return elapsed(e->ev[a], e->ev[b]); };
     e->stats.vit_ms = e->stats.vit_patches ? el(0, 1) : 0;
     e->stats.prefill_ms = e->stats.prefill_tokens ? el(2, 3) : 0;
     e->stats.decode_ms = e->stats.decode_steps ? el(4, 5) : 0;
     e->stats.total_ms = e->stats.decode_steps || e->stats.new_tokens ? el(6, 7) : 0;
     float a = 0;
-    for (int i = 0; i < e->attn_pairs; ++i) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e->attn_ev[2 * i], e->attn_ev[2 * i + 1]) == hipSuccess) a += ms;
-    }
+    for (int i = 0; i < e->attn_pairs; ++i) a += elapsed(e->attn_ev[2 * i], e->attn_ev[2 * i + 1]);
     e->stats.vit_attn_ms = a;
     e->stats.vit_attn_launches = e->attn_pairs;
     *out = e->stats;

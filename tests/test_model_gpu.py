@@ -512,3 +512,37 @@ def test_openai_server_on_the_real_engine_equals_direct_generate():
         assert d["choices"][0]["message"]["content"] == want[i], f"request {i}: server text differs from model.generate"
         assert 0 < d["usage"]["completion_tokens"] <= n_new and d["choices"][0]["finish_reason"] in ("length", "stop")
     model.engine.close()
+
+
+def test_engine_leaves_no_pending_hip_error_behind():
+    """PyTorch and RCCL call hipGetLastError after their own launches: an error the engine swallowed (e.g. hipEventElapsedTime on the
+    static-batch events after a slot-mode run, which made `bench.py --workload mixed64` die in dist.barrier under torchrun) would
+    surface there.  After a slot-mode run + stats(), and after a static run + stats(), the thread's last HIP error must be clear."""
+    import ctypes
+    from dots_ocr_amd.engine import Engine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    eng = Engine(cfg, max_batch=2, max_seq_len=512, max_patches=2048, max_prefill_tokens=1024)     # a fresh engine: no event recorded yet
+    eng.load_state_dict(random_state_dict(cfg, seed=4))
+    loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+    assert loaded, "no HIP runtime mapped?"
+    hip = ctypes.CDLL(loaded[0])                                             # the runtime instance torch and the engine already use
+    hip.hipGetLastError()                                                    # start clean
+    pv, grid, seqs = _inputs(cfg, [(1, 8, 8), (1, 6, 10), (1, 8, 12)], 5, seed=2)
+    reqs, off = [], 0
+    for g, ids in zip(grid.tolist(), seqs):
+        n = g[1] * g[2]
+        reqs.append(Request(ids.numpy().astype(np.int32), pv[off:off + n].cuda(), np.asarray([g], np.int64), 6))
+        off += n
+    outs = ContinuousBatcher(eng, eos_ids=()).run(reqs)
+    assert [len(o) for o in outs] == [6, 6, 6]
+    eng.stats()
+    assert hip.hipGetLastError() == 0, "a HIP error was left pending after a slot-mode run + stats()"
+    ids = seqs[0].numpy().astype(np.int32)
+    eng.generate(ids, np.asarray([len(ids)], np.int32), pv[:64].numpy(), np.asarray([[1, 8, 8]], np.int64), 4, ())
+    eng.stats()
+    assert hip.hipGetLastError() == 0, "a HIP error was left pending after a static run + stats()"
+    y = torch.ones(8, device="cuda") * 2                                      # what torch itself would have tripped over
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 16.0
+    eng.close()
