@@ -298,7 +298,9 @@ def main():
         res = {
             "metric": (f"pages/sec, dots.ocr 1.7B {'fp8 weights' if fp8 else 'bf16'}, chart->SVG page (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)"
                        if a.workload == "svg" else
-                       f"pages/sec, dots.ocr 1.7B bf16, A4@200dpi page batch (preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)"),
+                       f"pages/sec, dots.ocr 1.7B {'fp8' if fp8 else 'bf16'}, "
+                       f"{ {'a4': 'A4@200dpi page batch', 'mixed64': '64 mixed-size pages (continuous batching)', 'highres': 'high-res 1344x1344 page batch', 'tiny': 'tiny-dims plumbing run'}[a.workload] } "
+                       f"(preprocess + ViT + prefill + {a.max_new_tokens}-token greedy decode + detokenise)"),
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if mixed else "weak", "vs_baseline": None,
             "dtype": "fp8 e4m3 weights (per-output-channel fp32 scale) x bf16 activations, fp32 accumulate" if fp8 else "bf16", "data": "synthetic pages (PIL text lines) as uint8 pixels in HBM, seeded random weights at the checkpoint's dimensions",
