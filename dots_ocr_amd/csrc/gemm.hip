@@ -28,7 +28,10 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 128;            // one operand tile: 128 rows x 64 bf16
-constexpr int GROUP_M = 8;
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 8
+#endif
+constexpr int GROUP_M = GEMM_GROUP_M;
 
 DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
@@ -378,7 +381,7 @@ constexpr int SUBK = 32, SUB_OP = 256 * 64, SUB_STAGE = 2 * SUB_OP, PP_STAGES = 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
-    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles) {
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
 
     const int tid = threadIdx.x;
@@ -388,10 +391,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
     const int grp = w >> 2;                                     // waves w and w + 4 share a SIMD
 
     int bid = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-    const int per_group = GROUP_M * n_tiles;
+    const int per_group = group_m * n_tiles;
     const int g = bid / per_group;
-    const int first_m = g * GROUP_M;
-    const int gsz = min(m_tiles - first_m, GROUP_M);
+    const int first_m = g * group_m;
+    const int gsz = min(m_tiles - first_m, group_m);
     const int in_grp = bid - g * per_group;
     const int tm = first_m + in_grp % gsz;
     const int tn = in_grp / gsz;
@@ -522,7 +525,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_256pp_kernel(
     const uint8_t* __restrict__ A, const float* __restrict__ rowscale, const uint8_t* __restrict__ W, const float* __restrict__ colscale,
-    const bf16_t* __restrict__ bias, const bf16_t* R, void* Cout, int M, int N, int K, int ldc, int m_tiles, int n_tiles) {
+    const bf16_t* __restrict__ bias, const bf16_t* R, void* Cout, int M, int N, int K, int ldc, int m_tiles, int n_tiles, int group_m) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     constexpr int SUBK8 = 64;                                   // k per sub-tile (bytes per staged row)
 
@@ -533,10 +536,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256pp_kernel(
     const int grp = w >> 2;
 
     int bid = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-    const int per_group = GROUP_M * n_tiles;
+    const int per_group = group_m * n_tiles;
     const int g = bid / per_group;
-    const int first_m = g * GROUP_M;
-    const int gsz = min(m_tiles - first_m, GROUP_M);
+    const int first_m = g * group_m;
+    const int gsz = min(m_tiles - first_m, group_m);
     const int in_grp = bid - g * per_group;
     const int tm = first_m + in_grp % gsz;
     const int tn = in_grp / gsz;
@@ -631,6 +634,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256pp_kernel(
 
 }  // namespace
 
+// m-tiles per raster group of the 256-wide kernels: the group's activation panels (256 rows x K) should stay in the XCD's 4 MB L2
+// while its 32 CUs sweep the n-tiles.  Measured on the bench's shapes (tools/gemm_bench.py, GEMM_GROUP_M 2 / 4 / 8 / 16 / 32):
+// 768 KB panels (K = 1536 bf16) 8, 2.1 MB panels (K = 4224) 4 (-8 %), 4.5 MB panels (K = 8960) 2 (-4 %); 32 is 12 % slower everywhere.
+static int raster_group_m(int row_bytes) {
+    const int panel = 256 * row_bytes;
+    return panel >= (4 << 20) ? 2 : panel >= (3 << 19) ? 4 : GROUP_M;
+}
+
 template <int E>
 static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const float* colscale, const bf16_t* R, void* C,
                                 int M, int N, int K, int lda, int ldc) {
@@ -660,7 +671,7 @@ static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, co
         __atomic_fetch_or(&configured_pp, bit, __ATOMIC_RELEASE);
     }
     hipLaunchKernelGGL(gemm_bf16_256pp_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), PP_STAGES * SUB_STAGE, s, A, W, bias, colscale, R, C, M, N, K,
-                       lda, ldc, m_tiles, n_tiles);
+                       lda, ldc, m_tiles, n_tiles, raster_group_m(K * 2));
     return hipGetLastError();
 }
 
@@ -713,7 +724,7 @@ static hipError_t launch_fp8_t(hipStream_t s, const uint8_t* Aq, const float* ro
     }
     const int m_tiles = (M + BM2 - 1) / BM2, n_tiles = N / BN2;
     hipLaunchKernelGGL(gemm_fp8_256pp_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), PP_STAGES * SUB_STAGE, s, Aq, rowscale, Wq, colscale, bias, R, C, M, N, K,
-                       ldc, m_tiles, n_tiles);
+                       ldc, m_tiles, n_tiles, raster_group_m(K));
     return hipGetLastError();
 }
 
