@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const bf16_t* __restrict
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * K) return;
     const int m = idx / K, k = idx % K;
-    if (to_image) dst[xfrag_off(m, k, XR)] = src[idx];
-    else dst[idx] = src[xfrag_off(m, k, XR)];
+    if (to_image) dst[ximage_off(m, k, XR, K)] = src[idx];
+    else dst[idx] = src[ximage_off(m, k, XR, K)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
 #pragma unroll
     for (int s = 0; s < CMB_BATCH; ++s) acc += s < n_used ? pv[s] * wts[s] : 0.f;      // fixed order: deterministic
     for (int s = CMB_BATCH; s < n_used; ++s) acc += po[(size_t)s * stride] * wts[s];
-    out[xfrag_off(b, head * 128 + d, XR)] = f2bf(acc * inv_l);     // X image: the input of the o projection
+    out[ximage_off(b, head * 128 + d, XR, Hq * 128)] = f2bf(acc * inv_l);     // X image: the input of the o projection
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,13 +459,13 @@ hipError_t launch_pack_frag_qkv(hipStream_t s, const bf16_t* src, bf16_t* dst, i
 }
 
 hipError_t launch_pack_x(hipStream_t s, const bf16_t* src, bf16_t* x, int rows, int K) {
-    if (K % 8 != 0 || rows < 1 || rows > 16) return hipErrorInvalidValue;
+    if (K % 8 != 0 || rows < 1 || rows > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(convert_x_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, s, src, x, rows, K, rows <= 8 ? 8 : 16, 1);
     return hipGetLastError();
 }
 
 hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows, int K) {
-    if (K % 8 != 0 || rows < 1 || rows > 16) return hipErrorInvalidValue;
+    if (K % 8 != 0 || rows < 1 || rows > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(convert_x_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, s, x, dst, rows, K, rows <= 8 ? 8 : 16, 0);
     return hipGetLastError();
 }

@@ -24,6 +24,9 @@
 // workgroups anywhere: every output element is complete inside one workgroup, the residual add happens in place.
 // The consumer of a residual-stream row recomputes its RMS statistic itself; numerics are identical to the standalone
 // norm kernel (bf16(bf16(x*rstd)*w)).
+// Batches above 16 rows: gridDim.y = ceil(B / 16) — workgroup (x, t) handles rows 16t .. 16t+15 (one MFMA column tile) exactly like
+// a batch of <= 16 rows; the weights of a slice are then read once per tile, by workgroups running at the same time (the second
+// read is served by L2 / the Infinity Cache).  decode_layout.h: the X image of a tile sits at element offset t * 16 * K.
 // fp8 weights (quant.hip): every kernel is a template over the streamed fragment type WT — bf16x8 (16 B per lane and k-step) or
 // u32x2 (8 e4m3 bytes) — which is converted to the bf16 MFMA operand in registers (4 v_cvt_scalef32_pk_bf16_fp8, exact) when
 // its MFMA issues; the per-output-channel scale is one more small operand of step 1 and multiplies the reduced accumulator in
@@ -184,6 +187,10 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out,
                                                        int B, int H, int Hq, int Hkv, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // this workgroup's 16-row batch tile
+        const int t0 = 16 * blockIdx.y;
+        h += (size_t)t0 * H; ctx_len += t0; block_table += (size_t)t0 * max_pages; q_out += (size_t)t0 * Hq * 128; B = min(16, B - t0);
+    }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                 // [H/8][XR][8]
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [16 waves][64 lanes]
     const int lane = threadIdx.x & 63, wv = wave_id();
@@ -287,6 +294,10 @@ template <int G, typename WT>
 __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
                                                         bf16_t* __restrict__ h, int B, int N, int K, int XR) {
     __shared__ f32x4 red[16 * 64];
+    {   // this workgroup's 16-row batch tile
+        const int t0 = 16 * blockIdx.y;
+        X += (size_t)t0 * K; h += (size_t)t0 * N; B = min(16, B - t0);
+    }
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int half = blockIdx.x & 1, tile = blockIdx.x >> 1;
     const int KS = K / 32;
@@ -361,6 +372,10 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
                                                                    const WT* __restrict__ Wd, const float* __restrict__ wscale, bf16_t* __restrict__ act,
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // this workgroup's 16-row batch tile
+        const int t0 = 16 * blockIdx.y;
+        h += (size_t)t0 * H; act += (size_t)t0 * I; B = min(16, B - t0);
+    }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [GU_WAVES][2][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
@@ -443,6 +458,10 @@ __global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restri
                                                           const WT* __restrict__ Wd, const float* __restrict__ wscale, float* __restrict__ logits,
                                                           int B, int H, int V, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // this workgroup's 16-row batch tile
+        const int t0 = 16 * blockIdx.y;
+        h += (size_t)t0 * H; logits += (size_t)t0 * V; B = min(16, B - t0);
+    }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int n_tile = min((int)blockIdx.x * 16 + wv, V / 16 - 1);     // tail waves recompute the last tile (same values)
@@ -519,11 +538,11 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps) {
-    if (H % 32 || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+    if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
-    const dim3 grid((Hq + 2 * Hkv) * 16);
+    const dim3 grid((Hq + 2 * Hkv) * 16, (B + 15) / 16);
     if (wscale) {
         hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, u32x2>, lds_max, &attr[1]);
         if (e != hipSuccess) return e;
@@ -539,9 +558,9 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
 }
 
 hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K) {
-    if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > 16) return hipErrorInvalidValue;
+    if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
-    const dim3 grid(N / 8);
+    const dim3 grid(N / 8, (B + 15) / 16);
 #define PROJ_CASE(G)                                                                                                                   \
     do {                                                                                                                               \
         if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);  \
@@ -568,13 +587,13 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT> : dec_gateup_kernel<4, NC_MAX, WT>;
     hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+    hipLaunchKernelGGL(kern, dim3(I / 16, (B + 15) / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
     return hipGetLastError();
 }
 
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
                              int B, int H, int I, float eps) {
-    if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > 16) return hipErrorInvalidValue;
+    if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps)
                   : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps);
 }
@@ -588,13 +607,13 @@ static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     const size_t lds = (size_t)XR * H * 2;
     hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX, WT>, (size_t)16 * H * 2, &attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((dec_lmhead_kernel<NC_MAX, WT>), dim3((V / 16 + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, wscale, logits, B, H, V, eps, XR);
+    hipLaunchKernelGGL((dec_lmhead_kernel<NC_MAX, WT>), dim3((V / 16 + 15) / 16, (B + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, wscale, logits, B, H, V, eps, XR);
     return hipGetLastError();
 }
 
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
                              int B, int H, int V, float eps) {
-    if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > 16) return hipErrorInvalidValue;
+    if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     return wscale ? lmhead_launch(s, h, ln_w, (const u32x2*)Wd, wscale, logits, B, H, V, eps)
                   : lmhead_launch(s, h, ln_w, (const bf16x8*)Wd, wscale, logits, B, H, V, eps);
 }

@@ -16,7 +16,12 @@ constexpr int PAGE_ELEMS = PAGE * 128;     // per (kv head, K|V)
 // of the tile is 256 contiguous bytes (two whole lines).
 DEVI int fp8_lane_slot(int g, int i) { return ((i >> 3) * 4 + g) * 8 + (i & 7); }
 DEVI int xr_of(int B) { return B <= 8 ? 8 : 16; }
-DEVI size_t xfrag_off(int m, int k, int XR) { return ((size_t)(k >> 3) * XR + m) * 8 + (k & 7); }
+//            Batches above 16 rows are split into 16-ROW TILES (one MFMA column tile each): tile t = rows 16t .. 16t+15 is a complete
+//            XR = 16 image of its own at element offset t * 16 * K, and every dense decode kernel runs one workgroup set per tile
+//            (blockIdx.y), i.e. sees a batch of <= 16 rows.
+DEVI size_t xfrag_off(int m, int k, int XR) { return ((size_t)(k >> 3) * XR + m) * 8 + (k & 7); }       // inside one tile: m < 16
+DEVI size_t ximage_off(int m, int k, int XR, int K) { return (size_t)(m >> 4) * 16 * K + xfrag_off(m & 15, k, XR); }   // any row of the batch
+constexpr int MAX_DECODE_ROWS = 64;        // sequences per decode step (4 tiles)
 
 // 4 features (m, k..k+3), k % 4 == 0 -> X image (8-byte store)
 DEVI void store_frag4(bf16_t* __restrict__ xf, int m, int k, int XR, float a, float b, float c, float d) {

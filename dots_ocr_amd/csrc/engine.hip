@@ -167,8 +167,8 @@ struct DotsEngine {
     // [0, highest occupied slot] and only commits tokens for occupied, unfinished slots
     bool slot_mode = false;
     bool sel_dirty = true;
-    int slot_active[16] = {0};
-    int slot_limit[16] = {0};              // prompt length + generation cap of the slot's sequence
+    int slot_active[DOTS_MAX_BATCH] = {0};
+    int slot_limit[DOTS_MAX_BATCH] = {0};  // prompt length + generation cap of the slot's sequence
     int32_t *d_sel = nullptr, *d_sel_new = nullptr, *d_max_len = nullptr, *p_dst = nullptr;
     const int32_t* sel_now = nullptr;      // selection mask of the next select_tokens() call
     // captured decode steps, keyed by everything the capture bakes in: rows, KV splits, static batch (out_cap = row stride of
@@ -486,7 +486,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->p_cs, (size_t)e->TP * 64));
     CK(e->alloc(&e->p_pos, (size_t)e->TP));
     CK(e->alloc(&e->p_src, (size_t)e->TP));
-    CK(e->alloc(&e->p_last, (size_t)16));
+    CK(e->alloc(&e->p_last, (size_t)DOTS_MAX_BATCH));
     CK(e->alloc(&e->p_tiles, (size_t)(e->TP / 64 + c.max_batch + 1)));
     CK(e->alloc(&e->p_qblocks, (size_t)(e->TP / 128 + c.max_batch + 1) * c.num_heads));
 
@@ -498,7 +498,7 @@ int alloc_workspaces(DotsEngine* e) {
     e->n_pool_pages = (int)((pool_tokens + 63) / 64);
     e->pool_layer_elems = (size_t)(e->n_pool_pages + 1) * c.num_kv_heads * 2 * 8192;
     CK(e->alloc(&e->pool, e->pool_layer_elems * c.num_layers));
-    const int mb = std::max(c.max_batch, 16);
+    const int mb = (c.max_batch + 15) / 16 * 16;            // rows of the decode buffers: whole 16-row tiles
     CK(e->alloc(&e->block_table, (size_t)mb * e->max_pages));
     CK(e->alloc(&e->ctx_len, (size_t)mb));
     CK(e->alloc(&e->cur_tokens, (size_t)mb));
@@ -506,19 +506,19 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->out_lens, (size_t)mb));
     CK(e->alloc(&e->finished, (size_t)mb));
     CK(e->alloc(&e->eos_ids, (size_t)16));
-    CK(e->alloc(&e->d_sel, (size_t)16));
-    CK(e->alloc(&e->d_sel_new, (size_t)16));
-    CK(e->alloc(&e->d_max_len, (size_t)16));
-    CK(e->alloc(&e->p_dst, (size_t)16));
+    CK(e->alloc(&e->d_sel, (size_t)DOTS_MAX_BATCH));
+    CK(e->alloc(&e->d_sel_new, (size_t)DOTS_MAX_BATCH));
+    CK(e->alloc(&e->d_max_len, (size_t)DOTS_MAX_BATCH));
+    CK(e->alloc(&e->p_dst, (size_t)DOTS_MAX_BATCH));
     CK(e->alloc(&e->am_idx, (size_t)mb * 64));
     CK(e->alloc(&e->am_val, (size_t)mb * 64));
-    CK(e->alloc(&e->d_h, (size_t)16 * H));
-    CK(e->alloc(&e->d_q, (size_t)16 * Nq));
-    CK(e->alloc(&e->d_att, (size_t)16 * Nq));
-    CK(e->alloc(&e->d_act, (size_t)16 * c.intermediate_size));
-    CK(e->alloc(&e->d_logits, (size_t)16 * c.vocab_size));
-    CK(e->alloc(&e->d_part_o, (size_t)16 * c.num_heads * 64 * 128));
-    CK(e->alloc(&e->d_part_ml, (size_t)16 * c.num_heads * 64 * 2));
+    CK(e->alloc(&e->d_h, (size_t)mb * H));
+    CK(e->alloc(&e->d_q, (size_t)mb * Nq));
+    CK(e->alloc(&e->d_att, (size_t)mb * Nq));
+    CK(e->alloc(&e->d_act, (size_t)mb * c.intermediate_size));
+    CK(e->alloc(&e->d_logits, (size_t)mb * c.vocab_size));
+    CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
+    CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
     // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
     e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
@@ -698,7 +698,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
     const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, Nkv = Hkv * 128, NQKV = Nq + 2 * Nkv;
-    if (B < 1 || B > c.max_batch || B > 16) return e->fail(DOTS_E_CAPACITY, "batch %d exceeds max_batch %d (<= 16)", B, c.max_batch);
+    if (B < 1 || B > c.max_batch) return e->fail(DOTS_E_CAPACITY, "batch %d exceeds max_batch %d", B, c.max_batch);
     int64_t T = 0;
     std::vector<int> L(B), S(B);
     int rows = B;                                           // rows of the last-position / lm_head / selection stage
@@ -718,7 +718,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         }
     }
     if (T > e->TP) return e->fail(DOTS_E_CAPACITY, "packed prompt tokens %lld > max_prefill_tokens %lld", (long long)T, (long long)e->TP);
-    e->hp_pos.resize(T); e->hp_src.resize(T); e->hp_last.assign(16, 0);
+    e->hp_pos.resize(T); e->hp_src.resize(T); e->hp_last.assign(DOTS_MAX_BATCH, 0);
     int64_t t = 0, vis_used = 0;
     for (int b = 0; b < B; ++b) {
         for (int i = 0; i < L[b]; ++i, ++t) {
@@ -736,7 +736,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     build_worklists(L, Hq, e->hp_tiles, e->hp_qblocks, &Tpad, S.data());
     CK(hipMemcpyAsync(e->p_pos, e->hp_pos.data(), T * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_src, e->hp_src.data(), T * 4, hipMemcpyHostToDevice, s));
-    CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), 16 * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), DOTS_MAX_BATCH * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_tiles, e->hp_tiles.data(), e->hp_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_qblocks, e->hp_qblocks.data(), e->hp_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
     // ---- KV pages: a static batch resets every slot; a slot prefill reserves for its own sequences only
@@ -756,17 +756,17 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     }
     if (!slots) {
         e->slot_mode = false;
-        std::fill(e->slot_active, e->slot_active + 16, 0);
+        std::fill(e->slot_active, e->slot_active + DOTS_MAX_BATCH, 0);
         CK(hipMemcpyAsync(e->ctx_len, lens, B * 4, hipMemcpyHostToDevice, s));
-        CK(hipMemsetAsync(e->out_lens, 0, 16 * 4, s));
-        CK(hipMemsetAsync(e->finished, 0, 16 * 4, s));
+        CK(hipMemsetAsync(e->out_lens, 0, c.max_batch * 4, s));
+        CK(hipMemsetAsync(e->finished, 0, c.max_batch * 4, s));
     } else {
         if (!e->slot_mode) {                               // entering slot mode: every slot starts free
-            std::fill(e->slot_active, e->slot_active + 16, 0);
-            CK(hipMemsetAsync(e->ctx_len, 0, 16 * 4, s));
+            std::fill(e->slot_active, e->slot_active + DOTS_MAX_BATCH, 0);
+            CK(hipMemsetAsync(e->ctx_len, 0, c.max_batch * 4, s));
             e->slot_mode = true;
         }
-        int32_t sel_new[16] = {0};
+        int32_t sel_new[DOTS_MAX_BATCH] = {0};
         for (int b = 0; b < B; ++b) {
             sel_new[S[b]] = 1;
             CK(hipMemcpyAsync(e->ctx_len + S[b], lens + b, 4, hipMemcpyHostToDevice, s));
@@ -774,7 +774,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
             CK(hipMemsetAsync(e->out_lens + S[b], 0, 4, s));
             CK(hipMemsetAsync(e->finished + S[b], 0, 4, s));
         }
-        CK(hipMemcpyAsync(e->d_sel_new, sel_new, 16 * 4, hipMemcpyHostToDevice, s));
+        CK(hipMemcpyAsync(e->d_sel_new, sel_new, DOTS_MAX_BATCH * 4, hipMemcpyHostToDevice, s));
         CK(hipMemcpyAsync(e->p_dst, S.data(), B * 4, hipMemcpyHostToDevice, s));
     }
 
@@ -948,7 +948,7 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
     if (c.intermediate_size % 64 || c.v_intermediate % 64) return bad("intermediate sizes must be multiples of 64");
     if (c.hidden_size > 1536 || c.hidden_size % 256) return bad("hidden_size must be a multiple of 256 and <= 1536 (decode kernels keep a residual row in registers)");
     if (c.num_heads * 128 < 512 || c.intermediate_size < 512) return bad("projection K too small for the 16-way in-workgroup split");
-    if (c.max_batch < 1 || c.max_batch > 16) return bad("max_batch must be in [1,16]");
+    if (c.max_batch < 1 || c.max_batch > DOTS_MAX_BATCH) return bad("max_batch must be in [1,64]");
     if (c.max_seq_len < 64 || c.max_patches < 4 || c.max_prefill_tokens < 1) return bad("capacity fields too small");
     if (c.kv_pool_tokens < 0 || (c.kv_pool_tokens > 0 && c.kv_pool_tokens < 64)) return bad("kv_pool_tokens must be 0 (default) or >= 64");
     if (c.v_merge < 1 || c.v_temporal_patch != 1) return bad("unsupported vision patching");
@@ -1075,7 +1075,7 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
     hipGraphExec_t exec = nullptr;
     if (use_graph && max_new_tokens > 1) RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
-    std::vector<int32_t> fin(16);
+    std::vector<int32_t> fin(DOTS_MAX_BATCH);
     int steps = 0;
     for (int step = 1; step < max_new_tokens; ++step) {
         if (exec) CK(hipGraphLaunch(exec, s));
@@ -1143,9 +1143,9 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
         if (e->slot_active[b]) rows = b + 1;
     if (!rows) return e->fail(DOTS_E_STATE, "every slot is free");
     if (e->sel_dirty) {
-        int32_t sel[16];
-        for (int b = 0; b < 16; ++b) sel[b] = e->slot_active[b];
-        CK(hipMemcpyAsync(e->d_sel, sel, 16 * 4, hipMemcpyHostToDevice, s));
+        int32_t sel[DOTS_MAX_BATCH];
+        for (int b = 0; b < DOTS_MAX_BATCH; ++b) sel[b] = e->slot_active[b];
+        CK(hipMemcpyAsync(e->d_sel, sel, DOTS_MAX_BATCH * 4, hipMemcpyHostToDevice, s));
         e->sel_dirty = false;
     }
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);
@@ -1321,7 +1321,7 @@ int dots_get_last_tokens(DotsEngine* e, int32_t* out) {
     if (!e || !out) return DOTS_E_INVALID;
     if (e->B < 1) return e->fail(DOTS_E_STATE, "no prefilled batch");
     CK(hipSetDevice(e->device));
-    std::vector<int32_t> lens(16), ids((size_t)16 * std::max(1, e->out_cap));
+    std::vector<int32_t> lens(DOTS_MAX_BATCH), ids((size_t)DOTS_MAX_BATCH * std::max(1, e->out_cap));
     CK(hipMemcpyAsync(lens.data(), e->out_lens, e->B * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipMemcpyAsync(ids.data(), e->out_ids, (size_t)e->B * e->out_cap * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipStreamSynchronize(e->stream));
@@ -1535,17 +1535,18 @@ int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* 
 
 int dots_op_decode_attn(DotsEngine* e, const void* q, const void* pool_layer, const int32_t* ctx_len_dev, const int32_t* block_table_dev,
                         int max_pages, void* out, int B, int Hq, int Hkv, int max_seq_len) {
-    if (!e || !q || !pool_layer || !ctx_len_dev || !block_table_dev || !out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad decode_attn arguments") : DOTS_E_INVALID;
+    if (!e || !q || !pool_layer || !ctx_len_dev || !block_table_dev || !out || B < 1 || B > DOTS_MAX_BATCH) return e ? e->fail(DOTS_E_INVALID, "bad decode_attn arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
     const int n_splits = splits_for_ctx(max_seq_len);
     float *po = nullptr, *pml = nullptr;
     bf16_t* att = nullptr;
-    CK(sc.get(&po, (size_t)16 * Hq * n_splits * 128));
-    CK(sc.get(&pml, (size_t)16 * Hq * n_splits * 2));
-    CK(sc.get(&att, (size_t)16 * Hq * 128));
-    CK(hipMemsetAsync(po, 0xff, (size_t)16 * Hq * n_splits * 128 * 4, e->stream));      // NaN: a partial read without having been written shows up
-    CK(hipMemsetAsync(pml, 0xff, (size_t)16 * Hq * n_splits * 2 * 4, e->stream));
+    const size_t rb = (size_t)(B + 15) / 16 * 16;
+    CK(sc.get(&po, rb * Hq * n_splits * 128));
+    CK(sc.get(&pml, rb * Hq * n_splits * 2));
+    CK(sc.get(&att, rb * Hq * 128));
+    CK(hipMemsetAsync(po, 0xff, rb * Hq * n_splits * 128 * 4, e->stream));      // NaN: a partial read without having been written shows up
+    CK(hipMemsetAsync(pml, 0xff, rb * Hq * n_splits * 2 * 4, e->stream));
     CK(launch_decode_attn(e->stream, (const bf16_t*)q, (const bf16_t*)pool_layer, ctx_len_dev, block_table_dev, max_pages, po, pml, B, Hq, Hkv, n_splits,
                           1.0f / sqrtf(128.0f)));
     CK(launch_decode_attn_combine(e->stream, po, pml, ctx_len_dev, att, B, Hq, Hkv, n_splits));
@@ -1555,13 +1556,13 @@ int dots_op_decode_attn(DotsEngine* e, const void* q, const void* pool_layer, co
 }
 
 int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout, int B, int N, int K, int fp8) {
-    if (!e || !x || !w || !h_inout || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_proj arguments") : DOTS_E_INVALID;
+    if (!e || !x || !w || !h_inout || B < 1 || B > DOTS_MAX_BATCH) return e ? e->fail(DOTS_E_INVALID, "bad dec_proj arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
     bf16_t* xi = nullptr;
     void* wd = nullptr;
     float* wscale = nullptr;
-    CK(sc.get(&xi, (size_t)16 * K));
+    CK(sc.get(&xi, (size_t)(B + 15) / 16 * 16 * K));
     CK(launch_pack_x(e->stream, (const bf16_t*)x, xi, B, K));
     RET(op_weight(e, sc, (const bf16_t*)w, N, K, 0, 0, false, fp8, &wd, &wscale));
     CK(launch_dec_proj(e->stream, xi, wd, wscale, (bf16_t*)h_inout, B, N, K));
@@ -1571,14 +1572,14 @@ int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout,
 
 int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const void* gate_w, const void* up_w, void* act_out, int B, int H, int I, float eps,
                        int fp8) {
-    if (!e || !h || !ln_w || !gate_w || !up_w || !act_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_gateup arguments") : DOTS_E_INVALID;
+    if (!e || !h || !ln_w || !gate_w || !up_w || !act_out || B < 1 || B > DOTS_MAX_BATCH) return e ? e->fail(DOTS_E_INVALID, "bad dec_gateup arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
     bf16_t *w13 = nullptr, *act = nullptr;
     void* w13d = nullptr;
     float* wscale = nullptr;
     CK(sc.get(&w13, (size_t)2 * I * H));
-    CK(sc.get(&act, (size_t)16 * I));
+    CK(sc.get(&act, (size_t)(B + 15) / 16 * 16 * I));
     CK(launch_pack_w13(e->stream, (const bf16_t*)gate_w, (const bf16_t*)up_w, w13, I, H));
     RET(op_weight(e, sc, w13, (int64_t)2 * I, H, 0, 0, false, fp8, &w13d, &wscale));
     CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps));
@@ -1588,7 +1589,7 @@ int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const voi
 }
 
 int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const void* w, void* logits_out, int B, int H, int V, float eps, int fp8) {
-    if (!e || !h || !ln_w || !w || !logits_out || B < 1 || B > 16) return e ? e->fail(DOTS_E_INVALID, "bad dec_lmhead arguments") : DOTS_E_INVALID;
+    if (!e || !h || !ln_w || !w || !logits_out || B < 1 || B > DOTS_MAX_BATCH) return e ? e->fail(DOTS_E_INVALID, "bad dec_lmhead arguments") : DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     Scratch sc(e);
     void* wd = nullptr;

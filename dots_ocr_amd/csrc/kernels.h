@@ -5,6 +5,8 @@
 
 typedef uint16_t bf16_t;
 
+#define DOTS_MAX_BATCH 64     // sequences per decode step: 4 tiles of 16 rows (decode_layout.h MAX_DECODE_ROWS)
+
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4 };
 
 // ---- gemm.hip

@@ -52,7 +52,8 @@ typedef struct DotsConfig {
     float v_rms_eps, v_ln_eps;
     int32_t v_use_bias, v_post_norm;
     /* runtime capacity */
-    int32_t max_batch;        /* sequences decoded together (<= 16: one MFMA column tile of the decode kernels) */
+    int32_t max_batch;        /* sequences decoded together: <= 64; the decode kernels work in tiles of 16 rows (one MFMA column tile),
+                                 batches above 16 re-read each weight slice once per tile from L2 / the Infinity Cache */
     int32_t max_seq_len;      /* prompt + generated tokens per sequence */
     int64_t max_patches;      /* vision patches per dots_vit_forward call (workspace) */
     int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
@@ -216,7 +217,7 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv_dev, void* q_dev, void
                            int Hq, int Hkv, int rope2d, float theta);
 /* ---- single kernels of the decode step, at caller-chosen dimensions.  All tensors are device pointers in
  * the ROW-MAJOR layouts of the HF state dict / of a plain [B, features] activation; the MFMA fragment-order packing the
- * decode step uses (csrc/decode_layout.h) is applied inside with the engine's own pack kernels.  B <= 16.
+ * decode step uses (csrc/decode_layout.h) is applied inside with the engine's own pack kernels.  B <= 64.
  *
  * dots_op_dec_qkv      h [B,H] -> RMSNorm(ln_w) -> fused qkv projection wqkv [(Hq+2Hkv)*128, H] + bias -> 1-D RoPE at position
  *                      ctx_len[b] -> q_out bf16 [B, Hq*128]; the new key / value row of every sequence is appended to its

@@ -85,7 +85,8 @@ def _rope(x, pos):
 
 # ------------------------------------------------------------------------------------------------ dec_qkv
 @pytest.mark.parametrize("B,positions", [(1, [0]), (8, [1, 63, 64, 65, 5200, 6223, 32766, 127]), (9, [5200 + i for i in range(9)]),
-                                         (16, [0, 1, 63, 64, 65, 127, 128, 5199, 5200, 5201, 6223, 6224, 12345, 32766, 31, 32])])
+                                         (16, [0, 1, 63, 64, 65, 127, 128, 5199, 5200, 5201, 6223, 6224, 12345, 32766, 31, 32]),
+                                         (35, [(977 * i) % 7000 for i in range(35)])])                # three 16-row batch tiles, the last one ragged
 def test_dec_qkv_norm_proj_bias_rope_and_page_append(eng, B, positions):
     g = torch.Generator().manual_seed(100 + B)
     h = bf(torch.randn(B, H, generator=g) * 2)
@@ -191,6 +192,7 @@ def _attn_case(eng, ctxs, max_seq_len, seed, spike=False):
     ([5200 + 100 * i for i in range(9)], 6224),                  # B = 9: 16-row X image
     ([6223] * 16, 6224),                                         # B = 16, every page full but the last key
     ([32766, 5200, 64], 32768),                                  # 64 splits, 2 page rounds per wave for the long row
+    ([(613 * i) % 1500 + 1 for i in range(21)], 1600),           # B = 21: the combine writes two X-image tiles
 ])
 def test_decode_attention_matches_oracle(eng, ctxs, max_seq_len):
     _attn_case(eng, ctxs, max_seq_len, seed=sum(ctxs) + len(ctxs))
@@ -201,7 +203,7 @@ def test_decode_attention_dominant_late_key(eng):
 
 
 # ------------------------------------------------------------------------------------------------ projections
-@pytest.mark.parametrize("B", [1, 8, 9, 16])
+@pytest.mark.parametrize("B", [1, 8, 9, 16, 17, 40])      # 17 / 40: two and three 16-row batch tiles
 @pytest.mark.parametrize("N,K", [(H, HQ * 128), (H, I)])
 def test_dec_proj_residual(eng, B, N, K):
     g = torch.Generator().manual_seed(B * 31 + K)
@@ -217,7 +219,7 @@ def test_dec_proj_residual(eng, B, N, K):
         assert (hd.float().cpu() - ref.flip(0)).abs().max() > 0.1
 
 
-@pytest.mark.parametrize("B", [1, 8, 9, 16])
+@pytest.mark.parametrize("B", [1, 8, 9, 16, 17, 40])      # 17 / 40: two and three 16-row batch tiles
 def test_dec_gateup_swiglu(eng, B):
     g = torch.Generator().manual_seed(B + 77)
     h, ln_w = bf(torch.randn(B, H, generator=g) * 3), bf(1 + 0.1 * torch.randn(H, generator=g))
@@ -231,7 +233,7 @@ def test_dec_gateup_swiglu(eng, B):
     close(out, ref, rel=2 ** -6, abs_=2e-3, what="gate/up")
 
 
-@pytest.mark.parametrize("B", [1, 8, 9, 16])
+@pytest.mark.parametrize("B", [1, 8, 9, 16, 17, 40])      # 17 / 40: two and three 16-row batch tiles
 def test_dec_lmhead_logits(eng, B):
     g = torch.Generator().manual_seed(B + 5)
     h, ln_w = bf(torch.randn(B, H, generator=g) * 3), bf(1 + 0.1 * torch.randn(H, generator=g))
@@ -247,8 +249,8 @@ def test_dec_lmhead_logits(eng, B):
 
 def test_decode_kernels_reject_unsupported_shapes(eng):
     from dots_ocr_amd.engine import DotsEngineError
-    z = torch.zeros(17 * 2048, dtype=torch.bfloat16, device="cuda")
+    z = torch.zeros(65 * 2048, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(DotsEngineError):
-        eng.op_dec_proj(z.data_ptr(), z.data_ptr(), z.data_ptr(), 17, 64, 512)          # B > 16
+        eng.op_dec_proj(z.data_ptr(), z.data_ptr(), z.data_ptr(), 65, 64, 512)          # B > 64 (four 16-row tiles)
     with pytest.raises(DotsEngineError):
         eng.op_dec_gateup(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 2, 2048, 64, EPS)   # hidden > 1536

@@ -191,6 +191,36 @@ def test_batch_of_more_than_8_rows_uses_full_mfma_columns():
     eng.close()
 
 
+@pytest.mark.parametrize("B,mb", [(20, 24), (37, 40)])
+def test_batches_above_16_rows_run_in_tiles_and_stay_batch_invariant(B, mb):
+    """B > 16: the decode kernels run one workgroup set per 16-row tile (blockIdx.y), the X images are tiled (decode_layout.h).
+    Every sequence must decode exactly as it does alone — rows of the first tile, of a middle tile and of the ragged last tile —
+    and through the slot interface (continuous batching over more than 16 slots)."""
+    from dots_ocr_amd.engine import Engine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=23)
+    eng = Engine(cfg, max_batch=mb, max_seq_len=256, max_patches=8192, max_prefill_tokens=4096)
+    eng.load_state_dict(sd)
+    grids = [(1, 4, 4) if i % 3 else (1, 2, 6) for i in range(B)]
+    pv, grid, seqs = _inputs(cfg, grids, 4, seed=10)
+    ids = torch.cat(seqs).numpy().astype(np.int32)
+    lens = np.array([len(s) for s in seqs], np.int32)
+    n_new = 9
+    out, out_lens = eng.generate(ids, lens, pv.numpy(), grid.numpy(), max_new_tokens=n_new)
+    assert out_lens.tolist() == [n_new] * B
+    off = np.concatenate([[0], np.cumsum([g[1] * g[2] for g in grids])])
+    for b in sorted({0, 15, 16, 17, B // 2, B - 1}):
+        single, _ = eng.generate(seqs[b].numpy().astype(np.int32), lens[b:b + 1], pv[off[b]:off[b + 1]].numpy(), grid[b:b + 1].numpy(),
+                                 max_new_tokens=n_new)
+        assert np.array_equal(single[0], out[b]), f"row {b} of a batch of {B} differs from its single-sequence run"
+    reqs = [Request(seqs[b].numpy().astype(np.int32), pv[off[b]:off[b + 1]].cuda(), grid[b:b + 1].numpy(), n_new) for b in range(B)]
+    outs = ContinuousBatcher(eng, eos_ids=()).run(reqs)
+    for b in range(B):
+        assert np.array_equal(np.asarray(outs[b]), out[b]), f"slot run of sequence {b} differs from the static batch"
+    eng.close()
+
+
 def test_sampling_matches_softmax_and_respects_nucleus(setup):
     """Temperature / top-p sampling on the GPU: limits, reproducibility, distribution, nucleus."""
     cfg, sd, eng = setup
