@@ -211,3 +211,35 @@ def test_vision_block_composition_matches_transformers_qwen2_5_vl_block():
     # attention really is per image: moving the image boundaries changes the result
     other = om.vision_block(sd, "b.", x, cos.unsqueeze(1), sin.unsqueeze(1), [n], Hh, D, 1e-6, False)
     assert (other - ref).abs().max() > 1e-3
+
+
+def test_fp8_oracle_mode_definitions():
+    """The fp8 oracle mode's building blocks (what tests/test_fp8_gpu.py holds the engine to): per-row e4m3 quantisation is exact on
+    representable rows, saturates nowhere, leaves zero rows alone; a8 linear == explicit quantise-dequantise-matmul; the state-dict
+    transform touches exactly the linears (and copies a tied lm_head) and is idempotent."""
+    from dots_ocr_amd.config import DotsConfig
+    from dots_ocr_amd.weights import random_state_dict
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(37, 96, generator=g) * torch.logspace(-4, 2, 37).view(-1, 1)
+    w[5] = 0
+    q, s = om.quantize_rows_fp8(w)
+    assert q.abs().max() <= 448 and torch.isfinite(q).all()
+    assert torch.equal(q[5], torch.zeros(96)) and float(s[5]) == 1.0
+    assert torch.allclose(q.abs().amax(1)[s != 1.0], torch.full((36,), 448.0))            # the row maximum maps to the format's maximum
+    rel = ((q * s[:, None] - w).abs() / w.abs().amax(1, keepdim=True).clamp_min(1e-30)).max()
+    assert float(rel) <= 2 ** -4 + 1e-6                                                     # half an ulp of a 3-bit mantissa, relative to the row max
+    q2, s2 = om.quantize_rows_fp8(q * s[:, None])                                           # representable rows survive unchanged
+    assert torch.equal(q2, q) and torch.allclose(s2, s)
+    x = torch.randn(11, 96, generator=g)
+    xq, xs = om.quantize_rows_fp8(x)
+    assert torch.equal(om.linear(x, w, None, a8=True), (xq * xs[:, None]) @ w.t())
+    cfg = DotsConfig.tiny(layers=1, v_layers=1)
+    sd = random_state_dict(cfg, seed=1)
+    qsd = om.quantize_fp8_state_dict(sd)
+    changed = sorted(k for k in sd if not torch.equal(qsd[k].float(), sd[k].float()))
+    assert changed and all(k.endswith(om.FP8_LINEAR_SUFFIXES) for k in changed)
+    assert not any(k.startswith("vision_tower.patch_embed") or "norm" in k or k.endswith(".bias") or k == "model.embed_tokens.weight" for k in changed)
+    again = om.quantize_fp8_state_dict(qsd)
+    assert all(torch.allclose(again[k].float(), qsd[k].float(), rtol=1e-6, atol=0) for k in qsd)
+    tied = {k: v for k, v in sd.items() if k != "lm_head.weight"}
+    assert "lm_head.weight" in om.quantize_fp8_state_dict(tied) and torch.equal(tied["model.embed_tokens.weight"], sd["model.embed_tokens.weight"])
