@@ -31,6 +31,8 @@
 // u32x2 (8 e4m3 bytes) — which is converted to the bf16 MFMA operand in registers (4 v_cvt_scalef32_pk_bf16_fp8, exact) when
 // its MFMA issues; the per-output-channel scale is one more small operand of step 1 and multiplies the reduced accumulator in
 // the epilogue.  Half the bytes per step, the same arithmetic as the bf16(q) x scale GEMMs of prefill.
+#include <cstdlib>
+
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
@@ -367,8 +369,10 @@ constexpr int GU_WAVES = 4;      // 12 (single round) was measured slower: 12 wa
 constexpr int GU_EARLY = GU_EARLY_N;      // k-steps requested before the norm prologue; the rest right after it, when the row registers
                                  // are free: all I/16 workgroups are resident only at 3 waves per SIMD, i.e. <= 168 VGPRs
 
-template <int MAXR, int NC, typename WT>
-__global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
+// PAIRS (gate tile, up tile) pairs per workgroup: waves [p * GU_WAVES, (p + 1) * GU_WAVES) split the K of pair p; all PAIRS * GU_WAVES
+// waves share one norm prologue, so the residual rows are fetched and normalised by half as many workgroups when PAIRS = 2.
+template <int MAXR, int NC, typename WT, int PAIRS>
+__global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                                    const WT* __restrict__ Wd, const float* __restrict__ wscale, bf16_t* __restrict__ act,
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,11 +381,12 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
         h += (size_t)t0 * H; act += (size_t)t0 * I; B = min(16, B - t0);
     }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-    f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [GU_WAVES][2][64]
+    f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [PAIRS * GU_WAVES][2][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int pair = blockIdx.x, G = pair >> 1, a = pair & 1;
+    const int pw = wv / GU_WAVES, kw = wv % GU_WAVES;                             // pair inside the workgroup, K slice
+    const int pair = blockIdx.x * PAIRS + pw, G = pair >> 1, a = pair & 1;
     const int KS = H / 32;
-    const int k0 = wv * KS / GU_WAVES, k1 = (wv + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
+    const int k0 = kw * KS / GU_WAVES, k1 = (kw + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
     const int xstride = 4 * XR;
     const int ls = lane_slot<WT>(lane >> 4, lane & 15);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     const WT* wu = Wd + ((size_t)(G * 4 + 2 + a) * KS) * 64 + ls;
     TRACE(0);
     Rows<MAXR, NC> R;
-    rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, GU_WAVES, lane);
+    rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, PAIRS * GU_WAVES, lane);
     f32x4 scg = {1.f, 1.f, 1.f, 1.f}, scu = {1.f, 1.f, 1.f, 1.f};       // packed-W13 rows (G*4 + a)*16 + 4g + r (gate), + 32 (up)
     if constexpr (is_fp8<WT>::value) {
         scg = *reinterpret_cast<const f32x4*>(wscale + (G * 4 + a) * 16 + 4 * (lane >> 4));
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     pin_rows<MAXR, NC>(R);
     if constexpr (is_fp8<WT>::value) { PIN(scg); PIN(scu); }
     TRACE(1);
-    rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, GU_WAVES, lane);
+    rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, PAIRS * GU_WAVES, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = GU_EARLY; jj < GU_G; ++jj) {
@@ -431,10 +436,10 @@ __global__ __launch_bounds__(GU_WAVES * 64) void dec_gateup_kernel(const bf16_t*
     __syncthreads();
     TRACE(5);
     const int m = lane & 15, g = lane >> 4;
-    if (wv != 0 || m >= B) return;
+    if (kw != 0 || m >= B) return;
     f32x4 gs = ag, us = au;
 #pragma unroll
-    for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[(ww * 2) * 64 + lane]; us += red[(ww * 2 + 1) * 64 + lane]; }
+    for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[((pw * GU_WAVES + ww) * 2) * 64 + lane]; us += red[((pw * GU_WAVES + ww) * 2 + 1) * 64 + lane]; }
     if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
     float o[4];
 #pragma unroll
@@ -581,10 +586,23 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
                                 int B, int H, int I, float eps) {
     static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
+    const int v = B <= 8 ? 0 : 1;
+    // 2 pairs per workgroup (8 waves, two rows per wave) for the 16-row image: 14.7 vs 16.4 us at B = 16 (four rows per wave otherwise);
+    // at B <= 8 one pair per workgroup is faster (13.3 vs 13.9 us at B = 8, 11.9 vs 13.6 at B = 1).  DOTS_OCR_GATEUP_PAIRS=1/2 forces either.
+    static const int pairs_env = [] { const char* e = getenv("DOTS_OCR_GATEUP_PAIRS"); return e ? atoi(e) : 0; }();
+    const int pairs = pairs_env ? pairs_env : (B > 8 ? 2 : 1);
+    if (pairs == 2 && (I / 16) % 2 == 0) {
+        static uint32_t attr2[2] = {0, 0};
+        const size_t lds2 = (size_t)XR * H * 2 + 4 * GU_WAVES * 64 * sizeof(f32x4), lds2_max = (size_t)16 * H * 2 + 4 * GU_WAVES * 64 * sizeof(f32x4);
+        auto kern2 = v == 0 ? dec_gateup_kernel<1, NC_MAX, WT, 2> : dec_gateup_kernel<2, NC_MAX, WT, 2>;
+        hipError_t e2 = ensure_lds(kern2, lds2_max, &attr2[v]);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(kern2, dim3(I / 32, (B + 15) / 16), dim3(2 * GU_WAVES * 64), lds2, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)XR * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
     const size_t lds_max = (size_t)16 * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
-    const int v = B <= 8 ? 0 : 1;
-    auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT> : dec_gateup_kernel<4, NC_MAX, WT>;
+    auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT, 1> : dec_gateup_kernel<4, NC_MAX, WT, 1>;
     hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(I / 16, (B + 15) / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
