@@ -136,7 +136,7 @@ def main():
             a.max_new_tokens = 4096
     if a.workload == "mixed64" and "--batch" not in " ".join(sys.argv[1:]):
         a.batch = 32                                # sequence slots per rank (engine maximum 64): decode is latency-bound, extra rows are cheap.
-                                                    # 1 GPU: 2.90 / 3.40 / 3.85 / 4.00 pages/s with 8 / 16 / 32 / 64 slots
+                                                    # 1 GPU: 2.90 / 3.40 / 3.92 / 4.06 pages/s with 8 / 16 / 32 / 64 slots
     fp8 = bool(a.fp8) if a.fp8 is not None else a.workload == "svg"
     if a.gpus > 1 and "RANK" not in os.environ:
         respawn_under_torchrun(a)

@@ -24,9 +24,10 @@
 // workgroups anywhere: every output element is complete inside one workgroup, the residual add happens in place.
 // The consumer of a residual-stream row recomputes its RMS statistic itself; numerics are identical to the standalone
 // norm kernel (bf16(bf16(x*rstd)*w)).
-// Batches above 16 rows: gridDim.y = ceil(B / 16) — workgroup (x, t) handles rows 16t .. 16t+15 (one MFMA column tile) exactly like
-// a batch of <= 16 rows; the weights of a slice are then read once per tile, by workgroups running at the same time (the second
-// read is served by L2 / the Infinity Cache).  decode_layout.h: the X image of a tile sits at element offset t * 16 * K.
+// Batches above 16 rows: gridDim.x = ceil(B / 16) — workgroup (t, y) handles rows 16t .. 16t+15 (one MFMA column tile) exactly like
+// a batch of <= 16 rows.  The tile index is the FAST grid dimension, so the workgroups that read the same weight slice are dispatched
+// back to back and run at the same time: the slice comes from HBM once, the other tiles' reads are served by the Infinity Cache
+// (lm_head alone is 467 MB: with the tiles a whole grid apart every tile would stream it from HBM again).  decode_layout.h: the X image of a tile sits at element offset t * 16 * K.
 // fp8 weights (quant.hip): every kernel is a template over the streamed fragment type WT — bf16x8 (16 B per lane and k-step) or
 // u32x2 (8 e4m3 bytes) — which is converted to the bf16 MFMA operand in registers (4 v_cvt_scalef32_pk_bf16_fp8, exact) when
 // its MFMA issues; the per-output-channel scale is one more small operand of step 1 and multiplies the reduced accumulator in
@@ -190,13 +191,13 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
                                                        int B, int H, int Hq, int Hkv, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {   // this workgroup's 16-row batch tile
-        const int t0 = 16 * blockIdx.y;
+        const int t0 = 16 * blockIdx.x;
         h += (size_t)t0 * H; ctx_len += t0; block_table += (size_t)t0 * max_pages; q_out += (size_t)t0 * Hq * 128; B = min(16, B - t0);
     }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                 // [H/8][XR][8]
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [16 waves][64 lanes]
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int half = blockIdx.x & 1, tile = blockIdx.x >> 1, head = tile >> 3, j = tile & 7;
+    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1, head = tile >> 3, j = tile & 7;
     const int KS = H / 32;
     const int k0 = wv * KS / 16, k1 = (wv + 1) * KS / 16;
     const int m = lane & 15, g = lane >> 4;
@@ -297,11 +298,11 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
                                                         bf16_t* __restrict__ h, int B, int N, int K, int XR) {
     __shared__ f32x4 red[16 * 64];
     {   // this workgroup's 16-row batch tile
-        const int t0 = 16 * blockIdx.y;
+        const int t0 = 16 * blockIdx.x;
         X += (size_t)t0 * K; h += (size_t)t0 * N; B = min(16, B - t0);
     }
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int half = blockIdx.x & 1, tile = blockIdx.x >> 1;
+    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1;
     const int KS = K / 32;
     const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);
     const int m = lane & 15, g = lane >> 4;
@@ -377,14 +378,14 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {   // this workgroup's 16-row batch tile
-        const int t0 = 16 * blockIdx.y;
+        const int t0 = 16 * blockIdx.x;
         h += (size_t)t0 * H; act += (size_t)t0 * I; B = min(16, B - t0);
     }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [PAIRS * GU_WAVES][2][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int pw = wv / GU_WAVES, kw = wv % GU_WAVES;                             // pair inside the workgroup, K slice
-    const int pair = blockIdx.x * PAIRS + pw, G = pair >> 1, a = pair & 1;
+    const int pair = blockIdx.y * PAIRS + pw, G = pair >> 1, a = pair & 1;
     const int KS = H / 32;
     const int k0 = kw * KS / GU_WAVES, k1 = (kw + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
@@ -464,12 +465,12 @@ __global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restri
                                                           int B, int H, int V, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {   // this workgroup's 16-row batch tile
-        const int t0 = 16 * blockIdx.y;
+        const int t0 = 16 * blockIdx.x;
         h += (size_t)t0 * H; logits += (size_t)t0 * V; B = min(16, B - t0);
     }
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int n_tile = min((int)blockIdx.x * 16 + wv, V / 16 - 1);     // tail waves recompute the last tile (same values)
+    const int n_tile = min((int)blockIdx.y * 16 + wv, V / 16 - 1);     // tail waves recompute the last tile (same values)
     const int KS = H / 32;                                             // a multiple of LM_G (launcher)
     constexpr int LM_G = LmG<WT>::value;
     const WT* wp = Wd + ((size_t)n_tile * KS) * 64 + lane_slot<WT>(lane >> 4, lane & 15);
@@ -547,7 +548,7 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
     static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
-    const dim3 grid((Hq + 2 * Hkv) * 16, (B + 15) / 16);
+    const dim3 grid((B + 15) / 16, (Hq + 2 * Hkv) * 16);
     if (wscale) {
         hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, u32x2>, lds_max, &attr[1]);
         if (e != hipSuccess) return e;
@@ -565,7 +566,7 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
 hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
-    const dim3 grid(N / 8, (B + 15) / 16);
+    const dim3 grid((B + 15) / 16, N / 8);
 #define PROJ_CASE(G)                                                                                                                   \
     do {                                                                                                                               \
         if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);  \
@@ -597,7 +598,7 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
         auto kern2 = v == 0 ? dec_gateup_kernel<1, NC_MAX, WT, 2> : dec_gateup_kernel<2, NC_MAX, WT, 2>;
         hipError_t e2 = ensure_lds(kern2, lds2_max, &attr2[v]);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(kern2, dim3(I / 32, (B + 15) / 16), dim3(2 * GU_WAVES * 64), lds2, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+        hipLaunchKernelGGL(kern2, dim3((B + 15) / 16, I / 32), dim3(2 * GU_WAVES * 64), lds2, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
         return hipGetLastError();
     }
     const size_t lds = (size_t)XR * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
@@ -605,7 +606,7 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT, 1> : dec_gateup_kernel<4, NC_MAX, WT, 1>;
     hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(I / 16, (B + 15) / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+    hipLaunchKernelGGL(kern, dim3((B + 15) / 16, I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
     return hipGetLastError();
 }
 
@@ -625,7 +626,7 @@ static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     const size_t lds = (size_t)XR * H * 2;
     hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX, WT>, (size_t)16 * H * 2, &attr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((dec_lmhead_kernel<NC_MAX, WT>), dim3((V / 16 + 15) / 16, (B + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, wscale, logits, B, H, V, eps, XR);
+    hipLaunchKernelGGL((dec_lmhead_kernel<NC_MAX, WT>), dim3((B + 15) / 16, (V / 16 + 15) / 16), dim3(1024), lds, s, h, ln_w, Wd, wscale, logits, B, H, V, eps, XR);
     return hipGetLastError();
 }
 
