@@ -375,6 +375,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(
 // LDS image of a sub-tile operand: 256 rows x 64 B, 16-B slot XOR ((row >> 2) & 3): the 16 lanes of a ds_read_b128 group
 // (rows 0-3, 12-15, 20-27 / 4-11, 16-19, 28-31) land on 16 distinct slots of the 256-B bank row; applied on the DMA source
 // side (piece = 16 rows x 64 B, lane l = row l >> 2, slot l & 3) and again on the read.
+// Timing ablations (never defined in the product build; tools/build_variant_gemm.sh + tools/gemm_bench.py, results in DESIGN §5.1b):
+// -DPP_NO_DMA / PP_NO_LDS / PP_NO_MFMA / PP_NO_STORE drop one ingredient of the loop (the results are then garbage), -DPP_DMA_SAME makes
+// every DMA hit L2.  PINV keeps a value alive without using it.
 #define PINV(x) asm volatile("" ::"v"(x))
 constexpr int SUBK = 32, SUB_OP = 256 * 64, SUB_STAGE = 2 * SUB_OP, PP_STAGES = 4, PP_LOOKAHEAD = 3;
 
