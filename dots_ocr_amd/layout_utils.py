@@ -59,13 +59,41 @@ def is_legal_bbox(cells) -> bool:
     return all(c["bbox"][2] > c["bbox"][0] and c["bbox"][3] > c["bbox"][1] for c in cells)
 
 
-def draw_layout_on_image(image, cells):
-    """Outline every cell on a copy of the page (PIL; the reference draws with fitz)."""
-    from PIL import ImageDraw
-    img = image.copy()
-    d = ImageDraw.Draw(img)
-    for cell in cells:
-        x1, y1, x2, y2 = cell["bbox"]
-        d.rectangle([x1, y1, x2, y2], outline=(255, 0, 0), width=2)
-        d.text((x1 + 2, max(0, y1 - 10)), str(cell.get("category", "")), fill=(255, 0, 0))
-    return img
+# category -> RGB of the overlay (the reference's table, layout_utils.py:13-27; its 4th component is unused there as well)
+dict_layout_type_to_color = {
+    "Text": (0, 128, 0), "Picture": (255, 0, 255), "Caption": (255, 165, 0), "Section-header": (0, 255, 255),
+    "Footnote": (0, 128, 0), "Formula": (128, 128, 128), "Table": (255, 192, 203), "Title": (255, 0, 0),
+    "List-item": (0, 0, 255), "Page-header": (0, 128, 0), "Page-footer": (128, 0, 128), "Other": (165, 42, 42),
+    "Unknown": (0, 0, 0),
+}
+
+
+def draw_layout_on_image(image, cells, resized_height=None, resized_width=None, fill_bbox=True, draw_bbox=True):
+    """The page with every cell drawn on it in its category colour and labelled "<reading order>_<category>" to the right of its
+    top edge (reference layout_utils.py:30-110, which renders through a PDF page with fitz; here PIL, so the result is the same
+    picture up to font and anti-aliasing).  fill_bbox: translucent fill (30 %) instead of an outline; draw_bbox=False: labels only;
+    resized_height / resized_width: the boxes are in the coordinates of a page resized to that size and are scaled back."""
+    from PIL import Image, ImageDraw, ImageFont
+    base = image.convert("RGBA")
+    overlay = Image.new("RGBA", base.size, (0, 0, 0, 0))
+    d = ImageDraw.Draw(overlay)
+    sx = sy = 1.0
+    if resized_height and resized_width:
+        sx, sy = resized_width / base.width, resized_height / base.height
+    try:
+        font = ImageFont.load_default(size=20)
+    except TypeError:                                  # Pillow < 10.1: only the small bitmap font
+        font = ImageFont.load_default()
+    for order, cell in enumerate(cells):
+        x0, y0, x1, y1 = cell["bbox"]
+        if sx != 1.0 or sy != 1.0:
+            x0, y0, x1, y1 = int(x0 / sx), int(y0 / sy), int(x1 / sx), int(y1 / sy)
+        category = cell["category"]
+        rgb = dict_layout_type_to_color.get(category, (0, 128, 0))
+        if draw_bbox:
+            if fill_bbox:
+                d.rectangle([x0, y0, x1, y1], fill=rgb + (77,))            # 0.3 opacity
+            else:
+                d.rectangle([x0, y0, x1, y1], outline=rgb + (255,), width=1)
+        d.text((x1, y0), f"{order}_{category}", fill=rgb + (255,), font=font)
+    return Image.alpha_composite(base, overlay).convert("RGB")

@@ -459,3 +459,25 @@ def test_demo_display_helpers_resize_like_the_reference(tmp_path):
     assert not is_valid_image_path(str(tmp_path / "notes.txt")) and not is_valid_image_path(str(tmp_path / "missing.png"))
     with pytest.raises(FileNotFoundError):
         read_image(str(tmp_path / "missing.png"))
+
+
+def test_draw_layout_on_image_follows_the_reference_semantics():
+    """reference layout_utils.py:30-110: category colours, 30 % translucent fill or outline, "<order>_<category>" labels, boxes given
+    in resized coordinates scaled back, draw_bbox=False leaves the page pixels alone except for the labels."""
+    from dots_ocr.utils.layout_utils import dict_layout_type_to_color, draw_layout_on_image
+    page = Image.new("RGB", (400, 300), (255, 255, 255))
+    cells = [{"bbox": [10, 10, 200, 100], "category": "Title", "text": "x"}, {"bbox": [20, 120, 380, 280], "category": "Table"}]
+    out = draw_layout_on_image(page, cells)
+    assert out.size == page.size and out.mode == "RGB" and page.getpixel((50, 50)) == (255, 255, 255)          # input untouched
+    r, g, b = dict_layout_type_to_color["Title"][:3]
+    blend = tuple(round(255 * 0.7 + c * 0.3) for c in (r, g, b))
+    assert all(abs(a - e) <= 2 for a, e in zip(out.getpixel((50, 50)), blend))                                   # 30 % fill
+    assert out.getpixel((5, 5)) == (255, 255, 255) and out.getpixel((100, 200)) != (255, 255, 255)
+    edge = draw_layout_on_image(page, cells, fill_bbox=False)
+    assert edge.getpixel((10, 50)) == (r, g, b) and edge.getpixel((50, 50)) == (255, 255, 255)                 # outline only
+    scaled = draw_layout_on_image(page, cells, resized_height=600, resized_width=800, fill_bbox=False)
+    assert scaled.getpixel((5, 25)) == (r, g, b)                                                                 # x0 = 10 / 2
+    labels_only = draw_layout_on_image(page, cells, draw_bbox=False)
+    assert labels_only.getpixel((50, 50)) == (255, 255, 255)
+    unknown = draw_layout_on_image(page, [{"bbox": [0, 0, 50, 50], "category": "Sidebar"}])                      # unlisted category: green
+    assert unknown.getpixel((25, 25))[1] > unknown.getpixel((25, 25))[0]
