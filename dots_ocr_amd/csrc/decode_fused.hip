@@ -360,6 +360,73 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// dec_proj for long K at B <= 8 (down_proj: K = 8960, 17-18 k-steps per wave): the register version above runs three dependent
+// rounds of 6 k-steps because the X fragments (4 VGPRs per k-step) share the register file with the weights — the in-kernel trace
+// shows its waves finishing their K loops after 4.4 / 6.4 / 8.5 us (min / mean / max).  Here the wave's slice of the X image (8-row
+// image: 512 B per k-step, <= 10 KiB) is copied global -> LDS by DMA — no registers — and ALL of the wave's weight chunks are
+// requested in one round; B fragments come from LDS when their MFMA issues.  A wave reads back only the pieces it copied itself, so
+// its own "vmcnt(G)" is all the ordering the copy needs (no barrier).  Measured: 10.1 -> 9.5 us per launch at B = 8 (9.8 -> 9.4 at
+// B = 1).  What still holds it at ~9.5 us for 27.5 MB: every one of the 192 workgroups needs the whole 143 KB X image, i.e. as many
+// 128-B lines again as the weights (a row-0-only gather for B = 1 was tried: same number of lines, slower).
+// LDS: X image 16 K bytes | reduction buffer 16 KiB  (159 744 B at K = 8960: one workgroup per CU; the grid is N / 8 = 192).
+constexpr int PROJ_LDS_G = 18;
+template <typename WT>
+__global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
+                                                            bf16_t* __restrict__ h, int B, int N, int K) {
+    constexpr int G = PROJ_LDS_G, NP = G / 2 + 1, XR = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ximg = smem;                                                            // [K/8][8][8] bf16 = 16 K bytes
+    f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)16 * K);
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1;                      // B <= 8: a single batch tile (blockIdx.x == 0)
+    const int KS = K / 32;
+    const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);       // k1 - k0 <= G (launcher)
+    const int m = lane & 15, g = lane >> 4;
+    const bool epi = wv == 15 && m < B && g < 2;
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
+    bf16_t* hp = h + (size_t)min(m, B - 1) * N + tile * 16 + 8 * half + 4 * (g & 1);
+    TRACE(0);
+    const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + tile * 16 + 8 * half + 4 * (g & 1));
+    // this wave's k-steps live in image bytes [512 k0, 512 k1): 1 KiB pieces p0 .. (a piece shared with the neighbour wave is
+    // copied by both: same bytes)
+    const int p0 = k0 >> 1, plast = (KS - 1) >> 1;
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int pc = min(p0 + jj, plast);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (size_t)pc * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(ximg + pc * 1024), 16, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WT a[G];
+    weights_issue<G>(a, wp, k0, k1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");          // memory returns in order: residual, scales and the X pieces are in
+    const bf16x8* xp = reinterpret_cast<const bf16x8*>(ximg) + g * XR + (m & (XR - 1));
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int jj = 0; jj < G; jj += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj]), xp[(size_t)min(k0 + jj, KS - 1) * 4 * XR], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a[jj + 1]), xp[(size_t)min(k0 + jj + 1, KS - 1) * 4 * XR], acc1, 0, 0, 0);
+    }
+    TRACE(1);
+    red[wv * 64 + lane] = acc0 + acc1;
+    PIN(res);
+    if constexpr (is_fp8<WT>::value) PIN(sc);
+    __syncthreads();
+    TRACE(2);
+    if (!epi) return;
+    f32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) sum += red[sl * 64 + lane];
+    if constexpr (is_fp8<WT>::value) sum *= sc;
+    const u32x2 o = {pack_bf2(lo_bf(res[0]) + sum[0], hi_bf(res[0]) + sum[1]), pack_bf2(lo_bf(res[1]) + sum[2], hi_bf(res[1]) + sum[3])};
+    *reinterpret_cast<u32x2*>(hp) = o;
+    TRACE(3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // act = silu(gate) * up with gate/up = rmsnorm(h) @ W13^T.  grid I/16 workgroups x GU_WAVES waves (K-slices);
 // workgroup = one (gate tile, up tile) pair of the packed W13 (64-row groups: 32 gate rows | 32 up rows).
 constexpr int GU_G = 12;         // k-steps per wave held in registers (H = 1536: 48 k-steps / 4 waves)
@@ -572,6 +639,20 @@ hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const
         if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);  \
         else hipLaunchKernelGGL((dec_proj_kernel<G, bf16x8>), grid, dim3(1024), 0, s, X, (const bf16x8*)Wd, wscale, h, B, N, K, XR);       \
     } while (0)
+    static const bool no_lds = getenv("DOTS_OCR_PROJ_REG") != nullptr;            // A/B switch: the register-round kernel for long K too
+    const size_t lds_x = (size_t)16 * K + 16 * 64 * sizeof(f32x4);
+    if (!no_lds && B <= 8 && need > 4 && need <= PROJ_LDS_G && lds_x <= 160 * 1024) {
+        static uint32_t attr_l[2] = {0, 0};
+        hipError_t e;
+        if (wscale) {
+            if ((e = ensure_lds(dec_proj_lds_kernel<u32x2>, lds_x, &attr_l[1])) != hipSuccess) return e;
+            hipLaunchKernelGGL((dec_proj_lds_kernel<u32x2>), grid, dim3(1024), lds_x, s, X, (const u32x2*)Wd, wscale, h, B, N, K);
+        } else {
+            if ((e = ensure_lds(dec_proj_lds_kernel<bf16x8>, lds_x, &attr_l[0])) != hipSuccess) return e;
+            hipLaunchKernelGGL((dec_proj_lds_kernel<bf16x8>), grid, dim3(1024), lds_x, s, X, (const bf16x8*)Wd, wscale, h, B, N, K);
+        }
+        return hipGetLastError();
+    }
     if (need <= 1) PROJ_CASE(1);
     else if (need <= 2) PROJ_CASE(2);
     else if (need <= 3) PROJ_CASE(3);
