@@ -138,6 +138,11 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, 
  * parameters the reference passes to its vLLM backend (parser.py:27-28, model/inference.py:38-43).  Reproducible
  * from `seed` (counter-based: seed, batch slot, position). */
 int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed);
+/* Launch plan of the decode step for batches of <= 8 sequences (results are bit-identical in both modes): 1 = [qkv -> attention] and
+ * [o_proj -> gate|up] as ONE launch each, the second phase chained to the first by an in-launch hand-off (csrc/decode_flow.hip);
+ * 0 = one launch per phase (also what larger batches use).  Environment DOTS_OCR_FLOW sets the default.  A hand-off that times out
+ * fails the call that next synchronises with DOTS_E_HIP — never a hang. */
+int dots_set_decode_flow(DotsEngine* e, int mode);
 
 /* ---- Continuous batching (the serving loop the reference delegates to vLLM: README "vLLM inference", parser.py:138-166
  * fires one request per page at it and the server keeps its batch full).  The engine's max_batch KV slots are

@@ -1,0 +1,139 @@
+"""The fused decode launches (csrc/decode_flow.hip: [qkv -> attention] and [o_proj -> gate|up] as ONE launch each, the second role
+chained to the first by an in-launch hand-off) must produce EXACTLY the bits of the launch-per-phase kernels they replace
+(decode_fused.hip / decode.hip, parity-tested against the oracle in test_decode_kernels_gpu.py / test_fullsize_parity_gpu.py): same
+arithmetic, same reduction order, only the schedule and the transport of the activations differ.  Compared through the C ABI
+(dots_set_decode_flow): fp32 logits of every step, bitwise.
+
+Edge cases the hand-offs add: the token of the step is patched into the prefetched last KV page from the q|k|v hand-off buffer
+(first / last key of a page, a page that starts with this token), sequences of different lengths in one batch (idle splits),
+contexts beyond 4 x 64 pages (a wave walks several pages), fp8 weights, repeated graph replays (the sync words are re-armed by
+the memset node of every replay), and a batch of 9 that must fall back to the launch-per-phase kernels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from dots_ocr_amd.config import DotsConfig
+from dots_ocr_amd.weights import random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _prompts(cfg, lens, seed):
+    rng = np.random.default_rng(seed)
+    hi = min(cfg.vocab_size, cfg.image_token_id) - 1
+    ids = [rng.integers(0, hi, n).astype(np.int32) for n in lens]
+    return np.concatenate(ids), np.asarray(lens, np.int32)
+
+
+def _decode(eng, mode, ids, lens, n_steps):
+    eng.set_decode_flow(mode)
+    eng.prefill(ids, lens)
+    logits, tokens = [eng.get_logits().copy()], [eng.get_last_tokens().copy()]
+    for _ in range(n_steps):
+        eng.decode_step()
+        logits.append(eng.get_logits().copy())
+        tokens.append(eng.get_last_tokens().copy())
+    return logits, tokens
+
+
+def _assert_same(ref, got, what):
+    for s, (a, b) in enumerate(zip(ref[0], got[0])):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: logits differ at step {s} (max |d| {np.abs(a - b).max():.3e})"
+    for s, (a, b) in enumerate(zip(ref[1], got[1])):
+        assert np.array_equal(a, b), f"{what}: tokens differ at step {s}"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig.tiny(layers=3, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=5)
+    eng = Engine(cfg, max_batch=9, max_seq_len=1024, max_patches=1024, max_prefill_tokens=4096)
+    eng.load_state_dict(sd)
+    yield cfg, sd, eng
+    eng.close()
+
+
+@pytest.mark.parametrize("lens", [[70], [63, 64, 65, 1, 127, 128, 200, 190], [5, 300, 61]])
+def test_flow_modes_equal_launch_per_phase_bitwise(tiny, lens):
+    """Contexts that put the step's token at the last key of a page, the first key of a new page and in the middle; 6 steps so that
+    several sequences cross a page boundary while decoding."""
+    cfg, sd, eng = tiny
+    ids, ln = _prompts(cfg, lens, seed=len(lens))
+    ref = _decode(eng, 0, ids, ln, 6)
+    for mode in (1,):
+        _assert_same(ref, _decode(eng, mode, ids, ln, 6), f"flow mode {mode}, prompt lengths {lens}")
+
+
+def test_flow_under_graph_replay_and_generate(tiny):
+    """dots_generate replays ONE captured graph: the memset node re-arms the hand-off words on every replay."""
+    cfg, sd, eng = tiny
+    ids, ln = _prompts(cfg, [40, 90, 64, 33], seed=9)
+    out = {}
+    for mode in (0, 1):
+        eng.set_decode_flow(mode)
+        out[mode] = eng.generate(ids, ln, max_new_tokens=80)
+    for m in (1,):
+        for a, b in zip(out[0], out[m]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_batch_of_nine_falls_back(tiny):
+    cfg, sd, eng = tiny
+    ids, ln = _prompts(cfg, [20 + 3 * i for i in range(9)], seed=2)
+    ref = _decode(eng, 0, ids, ln, 3)
+    _assert_same(ref, _decode(eng, 1, ids, ln, 3), "B = 9 (launch-per-phase fallback)")
+
+
+def test_flow_walks_several_pages_per_wave_beyond_16k_context():
+    """max_seq_len > 16 384 caps the KV split at 64 workgroups of 4 waves: a wave then walks pages p, p + 256, ..."""
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=6)
+    eng = Engine(cfg, max_batch=2, max_seq_len=17408, max_patches=256, max_prefill_tokens=33000)
+    eng.load_state_dict(sd)
+    ids, ln = _prompts(cfg, [16500, 16383], seed=4)
+    ref = _decode(eng, 0, ids, ln, 3)
+    for mode in (1,):
+        _assert_same(ref, _decode(eng, mode, ids, ln, 3), f"16.5k-token contexts, mode {mode}")
+    eng.close()
+
+
+def test_flow_fp8_equals_launch_per_phase_bitwise():
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=7)
+    eng = Engine(cfg, max_batch=4, max_seq_len=512, max_patches=256, fp8_weights=True)
+    eng.load_state_dict(sd)
+    ids, ln = _prompts(cfg, [64, 100, 31], seed=8)
+    ref = _decode(eng, 0, ids, ln, 5)
+    ref2 = _decode(eng, 0, ids, ln, 5)
+    _assert_same(ref, ref2, "fp8, launch-per-phase run twice")
+    for mode in (1,):
+        got = _decode(eng, mode, ids, ln, 5)
+        for s_, (a, b) in enumerate(zip(ref[0], got[0])):
+            bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
+            if len(bad):
+                print(f"fp8 mode {mode} step {s_}: {len(bad)} logits differ, rows {sorted(set(bad[:, 0].tolist()))}, max |d| {np.abs(a - b).max():.3e}")
+        _assert_same(ref, got, f"fp8, flow mode {mode}")
+    eng.close()
+
+
+def test_flow_at_the_real_dimensions_bitwise():
+    """dots.ocr's LM dimensions (H 1536, 12:2 heads, I 8960, vocab 151 936; 4 layers of seeded random weights cover every role at its
+    real shape): B = 8, one context of 5.2 k tokens (25 KV splits like the bench) beside short ones that sit on, before and after a
+    page boundary; 5 steps."""
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig()
+    cfg.num_hidden_layers = 4
+    cfg.vision.num_hidden_layers = 1
+    sd = random_state_dict(cfg, seed=1, threads=16)
+    lens = [5247, 64, 1, 700, 63, 65, 128, 129]
+    eng = Engine(cfg, max_batch=8, max_seq_len=6288, max_patches=256, max_prefill_tokens=sum(lens) + 64)
+    eng.load_state_dict(sd)
+    ids, ln = _prompts(cfg, lens, seed=3)
+    ref = _decode(eng, 0, ids, ln, 5)
+    for mode in (1,):
+        _assert_same(ref, _decode(eng, mode, ids, ln, 5), f"real dimensions, flow mode {mode}")
+    eng.close()
