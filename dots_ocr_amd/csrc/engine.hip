@@ -148,6 +148,7 @@ struct DotsEngine {
     // ---- KV pool + decode state
     int max_pages = 0;                     // block-table width: pages of one sequence at max_seq_len
     int n_pool_pages = 0;                  // allocatable pages; page n_pool_pages is the scratch page idle rows write to
+    int kv_capped = 0;                     // sequences whose generation cap was lowered because the pool ran dry
     std::vector<int32_t> free_pages;       // LIFO free list
     std::vector<std::vector<int32_t>> slot_pages;
     bf16_t* pool = nullptr;                // [layers][n_pool_pages + 1][Hkv][2][8192]
@@ -173,7 +174,10 @@ struct DotsEngine {
     bool slot_mode = false;
     bool sel_dirty = true;
     int slot_active[DOTS_MAX_BATCH] = {0};
-    int slot_limit[DOTS_MAX_BATCH] = {0};  // prompt length + generation cap of the slot's sequence
+    int slot_limit[DOTS_MAX_BATCH] = {0};  // prompt length + generation cap of the slot's sequence (lowered when the page pool runs dry)
+    int slot_prompt[DOTS_MAX_BATCH] = {0}; // prompt length
+    int slot_ctx_ub[DOTS_MAX_BATCH] = {0}; // host-side upper bound of the slot's context: prompt + decode steps issued (finished rows stop earlier)
+    int slot_done[DOTS_MAX_BATCH] = {0};   // seen finished at the last poll: grows no more
     int32_t *d_sel = nullptr, *d_sel_new = nullptr, *d_max_len = nullptr, *p_dst = nullptr;
     const int32_t* sel_now = nullptr;      // selection mask of the next select_tokens() call
     // captured decode steps, keyed by everything the capture bakes in: rows, KV splits, static batch (out_cap = row stride of
@@ -566,6 +570,23 @@ bool reserve_pages(DotsEngine* e, int slot, int tokens) {
     return true;
 }
 
+// On-demand growth (continuous batching): make the sequence in `slot` own pages for `tokens` positions; returns the positions its pages
+// cover afterwards (< tokens when the pool ran dry).  *changed: the block-table row has to be uploaded.
+int grow_pages(DotsEngine* e, int slot, int tokens, bool* changed) {
+    auto& mine = e->slot_pages[slot];
+    const int need = std::min((tokens + 63) / 64, e->max_pages);
+    while ((int)mine.size() < need && !e->free_pages.empty()) {
+        e->hp_table[(size_t)slot * e->max_pages + mine.size()] = e->free_pages.back();
+        mine.push_back(e->free_pages.back());
+        e->free_pages.pop_back();
+        *changed = true;
+    }
+    return (int)mine.size() * 64;
+}
+// tokens a slot sequence reserves at admission: its prompt plus the first page-worth of generated tokens (the rest on demand)
+constexpr int KV_ADMIT_AHEAD = 64;
+int admit_tokens(const DotsEngine* e, int prompt, int max_new) { return std::min(prompt + std::min(max_new, KV_ADMIT_AHEAD), e->cfg.max_seq_len); }
+
 // sequences -> 64-token tiles and 128-row query blocks
 // (Tile64.seq = the KV slot of the sequence: seq_ids[s], or s itself)
 void build_worklists(const std::vector<int>& lens, int Hq, std::vector<Tile64>& tiles, std::vector<QBlock>& qblocks, int64_t* Tpad_used,
@@ -750,21 +771,32 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
     CK(hipMemcpyAsync(e->p_last, e->hp_last.data(), DOTS_MAX_BATCH * 4, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_tiles, e->hp_tiles.data(), e->hp_tiles.size() * sizeof(Tile64), hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(e->p_qblocks, e->hp_qblocks.data(), e->hp_qblocks.size() * sizeof(QBlock), hipMemcpyHostToDevice, s));
-    // ---- KV pages: a static batch resets every slot; a slot prefill reserves for its own sequences only
-    if (!slots)
+    // ---- KV pages: a static batch resets every slot and reserves prompt + generation cap (a closed batch: nothing competes for pages);
+    // a slot prefill reserves the prompt plus KV_ADMIT_AHEAD tokens for its own sequences only — the rest is taken page by page as the
+    // sequences actually grow (dots_slots_decode).  Entering slot mode returns the pages of the previous static batch first.
+    if (!slots || !e->slot_mode)
         for (int b = 0; b < (int)e->slot_pages.size(); ++b) release_pages(e, b);
+    const bool whole_table = !slots || !e->slot_mode;
     {
         int need = 0;
-        for (int b = 0; b < B; ++b) need += (std::min(L[b] + (slots ? max_new[b] : e->out_cap), c.max_seq_len) + 63) / 64;
+        for (int b = 0; b < B; ++b) need += ((slots ? admit_tokens(e, L[b], max_new[b]) : std::min(L[b] + e->out_cap, c.max_seq_len)) + 63) / 64;
         if (need > (int)e->free_pages.size()) {
             const int have = (int)e->free_pages.size();
-            if (!slots) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
+            if (whole_table) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
             return e->fail(DOTS_E_CAPACITY, "KV pool exhausted: these sequences need %d pages of 64 tokens, %d of %d are free", need, have, e->n_pool_pages);
         }
-        for (int b = 0; b < B; ++b) reserve_pages(e, S[b], std::min(L[b] + (slots ? max_new[b] : e->out_cap), c.max_seq_len));
-        if (!slots) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
+        for (int b = 0; b < B; ++b) reserve_pages(e, S[b], slots ? admit_tokens(e, L[b], max_new[b]) : std::min(L[b] + e->out_cap, c.max_seq_len));
+        if (whole_table) CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
         else for (int b = 0; b < B; ++b) CK(upload_table_row(e, S[b]));
     }
+    // from here on a failed launch must give the pages back (the slots are not marked occupied yet, so dots_slot_release would refuse them)
+    struct PageGuard {
+        DotsEngine* e; const std::vector<int>& S; bool slots, armed = true;
+        ~PageGuard() {
+            if (!armed || !slots) return;
+            for (int sl : S) { release_pages(e, sl); (void)upload_table_row(e, sl); }
+        }
+    } page_guard{e, S, slots != nullptr};
     if (!slots) {
         e->slot_mode = false;
         std::fill(e->slot_active, e->slot_active + DOTS_MAX_BATCH, 0);
@@ -823,6 +855,9 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         for (int b = 0; b < B; ++b) {
             e->slot_active[S[b]] = 1;
             e->slot_limit[S[b]] = L[b] + max_new[b];
+            e->slot_prompt[S[b]] = L[b];
+            e->slot_ctx_ub[S[b]] = L[b];
+            e->slot_done[S[b]] = 0;
         }
         e->sel_dirty = true;
         e->B = 0;                                          // the static-batch entry points need a static prefill first
@@ -830,6 +865,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         e->B = B;
         e->h_prompt_lens = L;
     }
+    page_guard.armed = false;
     e->steps_done = 0;
     e->vis_rows = 0;
     e->stats.prefill_tokens = T;
@@ -904,9 +940,15 @@ int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_
     CK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     int r = decode_step_launches(e, n_splits);
     hipError_t ce = hipStreamEndCapture(e->stream, &g.graph);
-    if (r != DOTS_OK) return r;
-    CK(ce);
-    CK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+    if (r != DOTS_OK || ce != hipSuccess) {
+        if (ce == hipSuccess && g.graph) hipGraphDestroy(g.graph);
+        if (r != DOTS_OK) return r;
+        CK(ce);
+    }
+    if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+        hipGraphDestroy(g.graph);
+        return e->fail(DOTS_E_HIP, "hipGraphInstantiate failed for the decode step");
+    }
     e->step_graphs.push_back(g);
     *exec = g.exec;
     return DOTS_OK;
@@ -1170,6 +1212,25 @@ int dots_slots_prefill(DotsEngine* e, const int32_t* slots, int n, const int32_t
     return prefill(e, input_ids, prompt_lens, n, slots, max_new_tokens);
 }
 
+// Enter slot mode with every slot free and every KV page in the pool (whatever a static batch or an abandoned serving loop left behind).
+int dots_slots_reset(DotsEngine* e) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    CK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    for (int b = 0; b < (int)e->slot_pages.size(); ++b) release_pages(e, b);
+    CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
+    std::fill(e->slot_active, e->slot_active + DOTS_MAX_BATCH, 0);
+    CK(hipMemsetAsync(e->ctx_len, 0, e->cfg.max_batch * 4, s));
+    CK(hipMemsetAsync(e->out_lens, 0, e->cfg.max_batch * 4, s));
+    CK(hipMemsetAsync(e->finished, 0, e->cfg.max_batch * 4, s));
+    CK(hipStreamSynchronize(s));
+    e->slot_mode = true;
+    e->sel_dirty = true;
+    e->B = 0;
+    return DOTS_OK;
+}
+
 int dots_slots_decode(DotsEngine* e, int n_steps) {
     if (!e) return DOTS_E_INVALID;
     if (!e->slot_mode) return e->fail(DOTS_E_STATE, "no slot has been prefilled");
@@ -1185,6 +1246,24 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
         for (int b = 0; b < DOTS_MAX_BATCH; ++b) sel[b] = e->slot_active[b];
         CK(hipMemcpyAsync(e->d_sel, sel, DOTS_MAX_BATCH * 4, hipMemcpyHostToDevice, s));
         e->sel_dirty = false;
+    }
+    // ---- paged KV: every running sequence gets the pages the next n_steps positions need, now.  Pool dry: the sequence keeps what it
+    // has and its generation cap is lowered to what its pages hold — it finishes there with "length", like HF generate at the
+    // context capacity (an admission policy that leaves head-room makes this rare: dots_ocr_amd/scheduler.py).
+    for (int b = 0; b < rows; ++b) {
+        if (!e->slot_active[b] || e->slot_done[b]) continue;
+        const int want = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b]);
+        bool changed = false;
+        const int have = grow_pages(e, b, want, &changed);
+        if (changed) CK(upload_table_row(e, b));
+        if (have < want) {
+            e->slot_limit[b] = have;
+            const int32_t cap = have - e->slot_prompt[b];                 // >= tokens generated so far: the pages cover the current context
+            CK(hipMemcpyAsync(e->d_max_len + b, &cap, 4, hipMemcpyHostToDevice, s));
+            CK(hipStreamSynchronize(s));                                     // `cap` is a stack variable
+            e->kv_capped += 1;
+        }
+        e->slot_ctx_ub[b] = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b]);
     }
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);
     e->B = rows;
@@ -1212,8 +1291,10 @@ int dots_slots_poll(DotsEngine* e, int32_t* finished, int32_t* out_lens) {
     CK(hipMemcpyAsync(out_lens, e->out_lens, mb * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipStreamSynchronize(e->stream));
     RET(flow_check(e));
-    for (int b = 0; b < mb; ++b)
+    for (int b = 0; b < mb; ++b) {
         if (!e->slot_mode || !e->slot_active[b]) { finished[b] = -1; out_lens[b] = 0; }      // -1: free slot
+        else if (finished[b]) e->slot_done[b] = 1;                                           // takes no more pages
+    }
     return DOTS_OK;
 }
 
@@ -1249,6 +1330,14 @@ int dots_kv_pool_info(DotsEngine* e, int32_t* total_pages, int32_t* free_pages) 
     if (!e || !total_pages || !free_pages) return DOTS_E_INVALID;
     *total_pages = e->n_pool_pages;
     *free_pages = (int32_t)e->free_pages.size();
+    return DOTS_OK;
+}
+
+int dots_slot_capacity(DotsEngine* e, int slot, int32_t* pages_owned, int32_t* token_limit) {
+    if (!e || !pages_owned || !token_limit) return DOTS_E_INVALID;
+    if (!e->slot_mode || slot < 0 || slot >= e->cfg.max_batch || !e->slot_active[slot]) return e->fail(DOTS_E_STATE, "slot %d is not occupied", slot);
+    *pages_owned = (int32_t)e->slot_pages[slot].size();
+    *token_limit = e->slot_limit[slot];
     return DOTS_OK;
 }
 

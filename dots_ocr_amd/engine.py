@@ -71,6 +71,8 @@ def _prototypes(lib):
         "dots_preprocess_image": (i32, [vp, vp, i32, i32, i32, i32, i32, P(i32), P(i32), i32, P(i32), P(i32), i32, P(f32), P(f32), f32, vp]),
         "dots_set_sampling": (i32, [vp, f32, f32, C.c_uint64]),
         "dots_set_decode_flow": (i32, [vp, i32]),
+        "dots_slot_capacity": (i32, [vp, i32, P(i32), P(i32)]),
+        "dots_slots_reset": (i32, [vp]),
         "dots_set_eos": (i32, [vp, P(i32), i32]),
         "dots_slots_prefill": (i32, [vp, P(i32), i32, P(i32), P(i32), P(i32)]),
         "dots_slots_decode": (i32, [vp, i32]),
@@ -115,7 +117,7 @@ def _prototypes(lib):
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
     "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_flow", "dots_get_logits",
-    "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info",
+    "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info", "dots_slot_capacity", "dots_slots_reset",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8", "dots_op_gemm_fp8",
@@ -309,6 +311,10 @@ class Engine:
         assert sl.shape == lens.shape == cap.shape and ids.shape[0] == int(lens.sum())
         self._ck(self.lib.dots_slots_prefill(self.h, _i32p(sl), sl.shape[0], _i32p(ids), _i32p(lens), _i32p(cap)), "dots_slots_prefill")
 
+    def slots_reset(self):
+        """Slot mode, every slot free, every KV page in the pool."""
+        self._ck(self.lib.dots_slots_reset(self.h), "dots_slots_reset")
+
     def slots_decode(self, n_steps: int):
         self._ck(self.lib.dots_slots_decode(self.h, int(n_steps)), "dots_slots_decode")
 
@@ -327,6 +333,13 @@ class Engine:
 
     def slot_release(self, slot: int):
         self._ck(self.lib.dots_slot_release(self.h, int(slot)), "dots_slot_release")
+
+    def slot_capacity(self, slot: int):
+        """(pages owned, limit on prompt + generated tokens) of an occupied slot; the limit is prompt + max_new_tokens unless the KV
+        pool ran dry while the sequence was growing."""
+        pg, lim = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.dots_slot_capacity(self.h, int(slot), C.byref(pg), C.byref(lim)), "dots_slot_capacity")
+        return pg.value, lim.value
 
     def kv_pool_info(self):
         """(total, free) pages of 64 tokens in the paged KV pool."""

@@ -36,9 +36,10 @@ class Request:
 class ContinuousBatcher:
     """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
 
-    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16):
+    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: int = 2):
         self.engine = engine
         self.chunk = max(1, int(chunk))
+        self.headroom_pages = max(0, int(headroom_pages))       # free KV pages kept per running sequence when admitting (see plan_admission)
         self.n_slots = int(engine.max_batch)
         self.max_patches = int(engine.max_patches)
         self.max_prefill_tokens = int(engine.max_prefill_tokens)
@@ -49,10 +50,13 @@ class ContinuousBatcher:
         self.decode_steps = 0
         self.admissions = 0
         engine.set_eos(list(eos_ids))
-        fin, _ = engine.slots_poll()                 # start from an empty engine (e.g. after a failed run)
-        for s in range(self.n_slots):
-            if fin[s] >= 0:
-                engine.slot_release(s)
+        if hasattr(engine, "slots_reset"):           # start from an empty engine: no occupied slot, every KV page in the pool
+            engine.slots_reset()                     # (a static batch or a failed run may have left both behind)
+        else:
+            fin, _ = engine.slots_poll()
+            for s in range(self.n_slots):
+                if fin[s] >= 0:
+                    engine.slot_release(s)
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: Request) -> int:
@@ -66,6 +70,9 @@ class ContinuousBatcher:
         req.input_ids = ids
         # like HF generate, stop at the context capacity instead of failing
         req.max_new_tokens = max(1, min(int(req.max_new_tokens), self.max_seq_len - ids.shape[0]))
+        if hasattr(self.engine, "kv_pool_info") and self._admit_pages(ids.shape[0], req.max_new_tokens) > self.engine.kv_pool_info()[0]:
+            raise ValueError(f"prompt of {ids.shape[0]} tokens needs {self._admit_pages(ids.shape[0], req.max_new_tokens)} KV pages, "
+                             f"the pool holds {self.engine.kv_pool_info()[0]}")
         rid = self._next_id
         self._next_id += 1
         self.pending.append((rid, req))
@@ -79,6 +86,11 @@ class ContinuousBatcher:
         return [s for s in range(self.n_slots) if s not in self.running]
 
     # ------------------------------------------------------------------ admission
+    ADMIT_AHEAD = 64                                 # tokens beyond the prompt dots_slots_prefill reserves (engine.hip KV_ADMIT_AHEAD)
+
+    def _admit_pages(self, prompt: int, max_new: int) -> int:
+        return (min(prompt + min(int(max_new), self.ADMIT_AHEAD), self.max_seq_len) + 63) // 64
+
     def plan_admission(self) -> List[Tuple[int, int, Request]]:
         """FIFO: pop requests while a slot is free and the group fits the ViT and prefill workspaces.
         Lowest slots first, so the decode graph covers as few rows as possible."""
@@ -90,10 +102,12 @@ class ContinuousBatcher:
             p, t = req.n_patches(), int(req.input_ids.shape[0])
             if group and (patches + p > self.max_patches or tokens + t > self.max_prefill_tokens):
                 break
-            need = (min(t + int(req.max_new_tokens), self.max_seq_len) + 63) // 64      # paged KV: prompt + generation cap, in 64-token pages
-            if need > pages_free:
-                if not group and not self.running:
-                    raise ValueError(f"request needs {need} KV pages, the pool holds {self.engine.kv_pool_info()[0]}")
+            # paged KV, on demand: a sequence reserves its prompt + ADMIT_AHEAD tokens now and grows page by page; admit only while every
+            # running sequence (and this one) could still take `headroom` more pages, so that a dry pool — which ends a sequence early
+            # at what its pages hold — stays the exception.  Nothing running: admit whatever fits (submit() checked that it can).
+            need = self._admit_pages(t, req.max_new_tokens)
+            reserve = self.headroom_pages * (len(self.running) + len(group) + 1) if (self.running or group) else 0
+            if need + reserve > pages_free:
                 break                                                                    # wait for a running sequence to return its pages
             pages_free -= need
             self.pending.popleft()
@@ -146,6 +160,10 @@ class ContinuousBatcher:
             if done:
                 return done
         if not self.running:
+            if self.pending:                         # nothing runs, nothing could be admitted: it never will be
+                rid, req = self.pending.popleft()
+                raise RuntimeError(f"request {rid} ({req.input_ids.shape[0]} prompt tokens, {req.n_patches()} patches) cannot be admitted "
+                                   f"into an empty engine (KV pool {self.engine.kv_pool_info() if hasattr(self.engine, 'kv_pool_info') else '?'})")
             return []
         self.engine.slots_decode(self.chunk)
         self.decode_steps += self.chunk

@@ -40,7 +40,9 @@ extern "C" {
 typedef struct DotsEngine DotsEngine;
 
 /* Mirrors the checkpoint's config.json (+ vision_config) that from_pretrained reads
- * (parser.py:68-74).  Nothing is hard-coded in the kernels except head_dim == 128. */
+ * (parser.py:68-74).  Hard-coded in the kernels: head_dim == 128; dots_create also requires hidden_size % 256 == 0 and
+ * hidden_size <= 1536 (the decode kernels keep a residual row in 3 x 16-byte chunks per lane), the same for the vision embed_dim's
+ * norm path — dots.ocr's 1536 / 1536 fit; a wider model needs NC_MAX raised in csrc/decode_dev.h. */
 typedef struct DotsConfig {
     /* language model (Qwen2 architecture) */
     int32_t hidden_size, num_layers, num_heads, num_kv_heads, head_dim, intermediate_size, vocab_size;
@@ -57,8 +59,10 @@ typedef struct DotsConfig {
     int32_t max_seq_len;      /* prompt + generated tokens per sequence */
     int64_t max_patches;      /* vision patches per dots_vit_forward call (workspace) */
     int64_t max_prefill_tokens; /* packed prompt tokens per dots_prefill call */
-    int64_t kv_pool_tokens;   /* paged KV cache: tokens the page pool holds across ALL sequences (pages of 64); a sequence reserves
-                                 prompt + generation cap when it is prefilled.  0 = max_batch * max_seq_len (never refuses) */
+    int64_t kv_pool_tokens;   /* paged KV cache: tokens the page pool holds across ALL sequences (pages of 64).  A static batch
+                                 (dots_prefill / dots_generate) reserves prompt + generation cap per sequence; a slot sequence
+                                 (dots_slots_prefill) reserves its prompt + 64 tokens and takes further pages on demand as it grows
+                                 (dots_slots_decode).  0 = max_batch * max_seq_len (never refuses) */
     int32_t fp8_weights;      /* != 0: dots_finalize_weights quantises every ViT-block / merger / LM linear and the lm_head to OCP e4m3 with
                                  one fp32 scale per output channel (scale = max|row| / 448; csrc/quant.hip).  The decode step streams
                                  the e4m3 bytes (half the HBM traffic) against bf16 activations; the ViT / prefill GEMMs quantise
@@ -149,16 +153,22 @@ int dots_set_decode_flow(DotsEngine* e, int mode);
  * independent sequences: a finished sequence is read out, its slot released and refilled by a new prefill while the other
  * slots keep decoding.  Any static-batch call (dots_prefill / dots_generate) resets every slot.
  *
+ * dots_slots_reset   enter slot mode with every slot free and every KV page back in the pool (a serving loop calls it once at start:
+ *                    the pages of an earlier static batch would otherwise count as used until the first dots_slots_prefill).
  * dots_set_eos       stop tokens for the slot calls.
  * dots_slots_prefill n new sequences (packed ids, like dots_prefill) into the free slots `slots[i]`, each with its own
  *                    cap on generated tokens; if the prompts hold image tokens, run dots_vit_forward for exactly these
  *                    sequences first.  Selects each new sequence's first token.
  * dots_slots_decode  n_steps decode steps over all occupied slots (one captured graph per (rows, kv-split) shape).
- *                    Finished sequences idle in place: their context is frozen and nothing more is appended.
+ *                    Finished sequences idle in place: their context is frozen and nothing more is appended.  Before the steps
+ *                    every running sequence is given the KV pages its next n_steps positions need (on-demand paging); if the pool
+ *                    is dry the sequence keeps its pages and its generation cap is lowered to what they hold — it finishes there
+ *                    (reason "length", as HF generate does at the context capacity); dots_slot_capacity reports the lowered cap.
  * dots_slots_poll    finished[b] = -1 free / 0 running / 1 finished, out_lens[b] = tokens generated so far; both
  *                    int32 [max_batch].  Synchronises the stream.
  * dots_slot_read     copies min(n, capacity) generated ids of one occupied slot, *n_out = n.
  * dots_slot_release  marks the slot free. */
+int dots_slots_reset(DotsEngine* e);
 int dots_set_eos(DotsEngine* e, const int32_t* eos_ids_host, int n_eos);
 int dots_slots_prefill(DotsEngine* e, const int32_t* slots_host, int n, const int32_t* input_ids_host,
                        const int32_t* prompt_lens_host, const int32_t* max_new_tokens_host);
@@ -167,8 +177,10 @@ int dots_slots_poll(DotsEngine* e, int32_t* finished_host, int32_t* out_lens_hos
 int dots_slot_read(DotsEngine* e, int slot, int32_t* out_ids_host, int capacity, int32_t* n_out);
 int dots_slot_release(DotsEngine* e, int slot);
 /* Paged KV pool: pages of 64 tokens in total / currently free (an admission policy checks this before dots_slots_prefill,
- * which refuses with DOTS_E_CAPACITY when prompt + max_new_tokens of the new sequences do not fit). */
+ * which refuses with DOTS_E_CAPACITY when prompt + 64 tokens of each new sequence do not fit). */
 int dots_kv_pool_info(DotsEngine* e, int32_t* total_pages, int32_t* free_pages);
+/* Pages an occupied slot owns and its current limit on prompt + generated tokens (prompt + max_new_tokens unless the pool ran dry). */
+int dots_slot_capacity(DotsEngine* e, int slot, int32_t* pages_owned, int32_t* token_limit);
 
 /* fp32 logits [B, vocab] of the most recent prefill/decode step (tolerance checks). */
 int dots_get_logits(DotsEngine* e, float* out_host);

@@ -159,9 +159,12 @@ def test_page_through_tower_prefill_and_decode_with_the_oracle_running_its_own_t
 
 
 def test_fp8_engine_at_real_dimensions_vs_fp8_oracle_and_vs_the_unquantised_oracle(world):
-    """fp8 configuration (BASELINE configs[4]) at 42 / 28 layers.  Two distances, both stated:
+    """fp8 configuration (BASELINE configs[4]) at 42 / 28 layers.  Three distances, all stated:
       * engine vs the fp8 oracle (same quantised weights, per-token e4m3 activations in tower + prefill): the kernels' error.
-        Activation quantisation is a step function, so it is looser than bf16: <= 4 % of the logit range (emulated) / 6 % (fp32).
+        Activation quantisation is a STEP function: a bf16-sized difference in an activation flips some e4m3 roundings (each flip
+        moves that element by 2^-3 relative), and 70 layers amplify it.  The yardstick is therefore the fp8 oracle's OWN sensitivity
+        to bf16 rounding — the distance between its bf16-emulated and its fp32 evaluation of the same quantised model (measured
+        here: both oracles run): the engine must be no farther from either than 1.5 x that distance (floor 4 % of the logit range).
       * engine vs the UNQUANTISED fp32 oracle: what fp8 costs the model — not a kernel property; asserted only loosely
         (<= 25 % of the logit range on these random weights, whose logits are nearly flat) and REPORTED."""
     from dots_ocr_amd.synthetic import synth_prompt_ids
@@ -176,7 +179,7 @@ def test_fp8_engine_at_real_dimensions_vs_fp8_oracle_and_vs_the_unquantised_orac
     _, q_f32 = om.generate(qsd, cfg, t_ids, t_pv, t_thw, n_steps, emulate_bf16=False, forced_tokens=tk, return_logits=True, fp8_act=True)
     del qsd
     _, u_f32 = om.generate(sd32, cfg, t_ids, t_pv, t_thw, n_steps, emulate_bf16=False, forced_tokens=tk, return_logits=True)
-    w_emu = w_f32 = w_unq = 0.0
+    w_emu = w_f32 = w_unq = w_oo = 0.0
     same_unq = 0
     for s in range(n_steps):
         got = torch.from_numpy(lg[s])
@@ -184,12 +187,17 @@ def test_fp8_engine_at_real_dimensions_vs_fp8_oracle_and_vs_the_unquantised_orac
         w_emu = max(w_emu, float((got - q_emu[s]).abs().max()) / rng)
         w_f32 = max(w_f32, float((got - q_f32[s]).abs().max()) / rng)
         w_unq = max(w_unq, float((got - u_f32[s]).abs().max()) / rng)
+        w_oo = max(w_oo, float((q_emu[s] - q_f32[s]).abs().max()) / rng)
         same_unq += int(tk[s] == int(u_f32[s].argmax()))
     REPORT["fp8_page_583x550_end_to_end"] = {
-        "steps": n_steps, "max_err_over_logit_range": {"vs_fp8_oracle_emulated": w_emu, "vs_fp8_oracle_fp32": w_f32, "vs_unquantised_fp32_oracle": w_unq},
+        "steps": n_steps, "max_err_over_logit_range": {"vs_fp8_oracle_emulated": w_emu, "vs_fp8_oracle_fp32": w_f32, "vs_unquantised_fp32_oracle": w_unq,
+                                              "fp8_oracle_emulated_vs_fp8_oracle_fp32": w_oo},
         "tokens_equal_to_unquantised_oracle_argmax": same_unq,
-        "tolerance": "4 % / 6 % of the logit range vs the fp8 oracle (emulated / fp32); vs the unquantised oracle reported, loosely bounded at 25 %"}
-    print(f"fp8 at real dims: {w_emu:.4f} / {w_f32:.4f} of the logit range vs the fp8 oracle (emulated / fp32), {w_unq:.4f} vs the unquantised fp32 oracle; "
+        "tolerance": "vs either fp8 oracle: max(4 %, 1.5 x the distance between the two fp8 oracles) of the logit range; vs the unquantised oracle "
+                     "reported, loosely bounded at 25 %"}
+    print(f"fp8 at real dims: {w_emu:.4f} / {w_f32:.4f} of the logit range vs the fp8 oracle (emulated / fp32; the two oracles differ by {w_oo:.4f}), "
+          f"{w_unq:.4f} vs the unquantised fp32 oracle; "
           f"{same_unq}/{n_steps} tokens equal the unquantised oracle's arg max")
-    assert w_emu < 0.04 and w_f32 < 0.06
+    tol = max(0.04, 1.5 * w_oo)
+    assert w_emu < tol and w_f32 < tol, f"engine {w_emu:.4f} / {w_f32:.4f} vs tolerance {tol:.4f}"
     assert w_unq < 0.25
