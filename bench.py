@@ -69,8 +69,10 @@ def respawn_under_torchrun(a):
 def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
     """The fp32 CPU oracle (PyTorch restatement of the reference's HF path, oracle/model.py) timed on a BOUNDED sample of the
     SAME unit of work — one full A4 page with its 5 200-token prompt — and extrapolated exactly by layer count: every
-    ViT block costs the same, every LM layer costs the same, every decode step (at fixed context) costs the same.  Timed:
-    the tower with 0 and with 1 block, the LM prefill with 0 and with 1 layer, 4 decode steps with 0 and with 1 layer.
+    ViT block costs the same, every LM layer costs the same, every decode step (at fixed context) costs the same.  Timed with a
+    FIXED thread count: the tower with 1 and with 3 blocks, the LM prefill with 1 and with 3 layers, 4 decode steps with 1 and
+    with 3 layers (per-layer cost = half the difference: two layers' worth of signal instead of the 0-vs-1 difference of round 2);
+    the tower pair is timed twice and the spread reported.  All raw timings are in the record.
     Checker code used only as the baseline being reported, never on the product path."""
     import copy
     import torch
@@ -80,8 +82,9 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
     pv, thw = preprocess_image(page)
     t_ids = torch.from_numpy(ids.astype(np.int64))
     grid = torch.tensor([thw])
-    keep = lambda name: (not name.startswith("vision_tower.blocks.") or name.startswith("vision_tower.blocks.0.")) and \
-        (not name.startswith("model.layers.") or name.startswith("model.layers.0."))
+    first3 = lambda name, pre: any(name.startswith(f"{pre}{i}.") for i in range(3))
+    keep = lambda name: (not name.startswith("vision_tower.blocks.") or first3(name, "vision_tower.blocks.")) and \
+        (not name.startswith("model.layers.") or first3(name, "model.layers."))
     sd = {k: v.float() for k, v in sd_bf16.items() if keep(k)}
 
     def cfg_with(v_layers, layers):
@@ -93,30 +96,43 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
         t0 = time.perf_counter()
         out = fn()
         return time.perf_counter() - t0, out
+    raw = {"vit_1_block_s": [], "vit_3_blocks_s": []}
     with torch.no_grad():
-        t_v0, _ = timed(lambda: om.vision_tower(sd, cfg_with(0, 0), torch.from_numpy(pv), grid))
-        t_v1, vis = timed(lambda: om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv), grid))
+        om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv[:2048]), torch.tensor([[1, 32, 64]]))       # thread pool / allocator warm-up
+        vis = None
+        for _ in range(2):
+            t1, vis = timed(lambda: om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv), grid))
+            t3, _ = timed(lambda: om.vision_tower(sd, cfg_with(3, 0), torch.from_numpy(pv), grid))
+            raw["vit_1_block_s"].append(t1)
+            raw["vit_3_blocks_s"].append(t3)
         emb = om.build_embeds(sd, cfg, t_ids, vis)
         n_dec = 4
         res = {}
-        for layers in (0, 1):
+        for layers in (1, 3):
             c = cfg_with(1, layers)
-            cache = om.KVCache(max(1, layers))
+            cache = om.KVCache(layers)
             t_p, logits = timed(lambda: om.lm_forward(sd, c, emb, cache))
             tok = torch.tensor([int(torch.argmax(logits[0]))])
             t_d, _ = timed(lambda: [om.lm_forward(sd, c, sd["model.embed_tokens.weight"][tok], cache) for _ in range(n_dec)])
             res[layers] = (t_p, t_d / n_dec)
+            raw[f"prefill_{layers}_layers_s"], raw[f"decode_step_{layers}_layers_s"] = t_p, t_d / n_dec
     VL, LL = cfg.vision.num_hidden_layers, cfg.num_hidden_layers
-    t_vit = t_v0 + (t_v1 - t_v0) * VL
-    t_prefill = res[0][0] + (res[1][0] - res[0][0]) * LL
-    t_step = res[0][1] + (res[1][1] - res[0][1]) * LL
+
+    def extrapolate(t_one, t_three, n):                      # t(n) = t_one + (n - 1) * per_layer
+        return t_one + (n - 1) * (t_three - t_one) / 2.0
+    vit_runs = [extrapolate(a, b, VL) for a, b in zip(raw["vit_1_block_s"], raw["vit_3_blocks_s"])]
+    t_vit = sum(vit_runs) / len(vit_runs)
+    t_prefill = extrapolate(res[1][0], res[3][0], LL)
+    t_step = extrapolate(res[1][1], res[3][1], LL)
     t_page = t_vit + t_prefill + t_step * (max_new_tokens - 1)
-    measured = t_v0 + t_v1 + sum(r[0] + r[1] * n_dec for r in res.values())
+    measured = sum(raw["vit_1_block_s"]) + sum(raw["vit_3_blocks_s"]) + sum(r[0] + r[1] * n_dec for r in res.values())
+    spread = (max(vit_runs) - min(vit_runs)) / t_vit
     return {"value": 1.0 / t_page, "unit": "pages/s", "cores": cores, "kind": "port",
             "sample": f"fp32 oracle on ONE full synthetic A4 page ({pv.shape[0]} patches, {len(ids)} prompt tokens, {max_new_tokens} new tokens), "
-                      f"{measured:.1f} s measured: ViT with 0 and 1 of {VL} blocks, LM prefill and {n_dec} decode steps with 0 and 1 of {LL} layers; "
-                      f"extrapolated by layer count to {t_page:.0f} s per page (ViT {t_vit:.0f} s, prefill {t_prefill:.0f} s, "
-                      f"decode {t_step * 1e3:.0f} ms/token = {1.0 / t_step:.2f} tok/s)"}
+                      f"{measured:.1f} s measured with {cores} threads: ViT with 1 and 3 of {VL} blocks (twice; the two extrapolations differ by "
+                      f"{spread * 100:.1f} %), LM prefill and {n_dec} decode steps with 1 and 3 of {LL} layers; extrapolated by layer count to "
+                      f"{t_page:.0f} s per page (ViT {t_vit:.0f} s, prefill {t_prefill:.0f} s, decode {t_step * 1e3:.0f} ms/token = {1.0 / t_step:.2f} tok/s)",
+            "raw_seconds": {k: ([round(x, 3) for x in v] if isinstance(v, list) else round(v, 4)) for k, v in raw.items()}}
 
 
 def mixed_pages(n_total, seed=2025):
@@ -167,7 +183,8 @@ def main():
     mixed = a.workload == "mixed64"
     B = a.batch
     t_setup = time.perf_counter()
-    sd = random_state_dict(cfg, seed=a.seed, threads=min(32, os.cpu_count() or 8))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    sd = random_state_dict(cfg, seed=a.seed, threads=max(2, min(32, (os.cpu_count() or 8) // max(1, local_world))))    # N ranks share the host's cores
     v = cfg.vision
     factor = v.patch_size * v.spatial_merge_size
 
@@ -312,7 +329,15 @@ def main():
             res["config"] = {"workload": "mixed64: 64 pages " + ", ".join(f"{n}x {w}x{h}" for (w, h), n in sorted(Counter(sizes_all).items())) +
                                          f"; cost-sharded (LPT) over {world} rank(s), continuous batching over {slots} slots per rank, "
                                          f"max_new_tokens={a.max_new_tokens}, EOS disabled",
-                             "pages_per_gpu": [len(s) for s in shards], "parallelism": f"dp{world}"}
+                             "pages_per_gpu": [len(s) for s in shards], "slots_per_gpu": slots,
+                             "occupied_slots_per_gpu_at_start": [min(slots, len(s)) for s in shards], "parallelism": f"dp{world}"}
+            occ = max(min(slots, len(s)) for s in shards)
+            res["scaling_note"] = (
+                f"strong scaling of a FIXED 64-page job: a rank holding {max(len(s) for s in shards)} pages decodes at most {occ} sequences at a time, and decode "
+                "is latency-bound (a step costs nearly the same for 8 as for 32 rows), so the per-GPU rate falls with the slot occupancy, not with "
+                "the interconnect (the only collective is the final KB-sized gather).  1-GPU rates of this job by slot count, measured "
+                "(profiles/r02_bench_mixed64_*.json, bench.py --workload mixed64 --batch S): 2.90 / 3.40 / 3.92 / 4.06 pages/s at S = 8 / 16 / 32 / 64. "
+                "The like-for-like 1-GPU denominator for an 8-rank run (8 pages per rank) is the S = 8 figure, not the S = 32 default.")
         else:
             res["config"] = {"workload": f"{a.workload}: {B} pages/GPU of {size[0]}x{size[1]} px -> {n_patches[0]} patches, "
                                          f"{len(prompts[0])} prompt tokens/page, max_new_tokens={a.max_new_tokens}, EOS disabled",
