@@ -481,3 +481,100 @@ def test_draw_layout_on_image_follows_the_reference_semantics():
     assert labels_only.getpixel((50, 50)) == (255, 255, 255)
     unknown = draw_layout_on_image(page, [{"bbox": [0, 0, 50, 50], "category": "Sidebar"}])                      # unlisted category: green
     assert unknown.getpixel((25, 25))[1] > unknown.getpixel((25, 25))[0]
+
+
+# ---------------------------------------------------------------------------------------------- PDF rasterisation
+def _pdf(objects, compressed=()):
+    """Serialise {num: (dict_source, stream_bytes | None)} into a PDF; the numbers in `compressed` go into one object stream (PDF 1.5)."""
+    import zlib
+    out = bytearray(b"%PDF-1.5\n%\xe2\xe3\xcf\xd3\n")
+    for num, (src, stream) in objects.items():
+        if num in compressed:
+            continue
+        out += b"%d 0 obj\n%s\n" % (num, src)
+        if stream is not None:
+            out += b"stream\n" + stream + b"\nendstream\n"
+        out += b"endobj\n"
+    if compressed:
+        bodies, head, off = [], [], 0
+        for num in compressed:
+            body = objects[num][0] + b"\n"
+            head.append(b"%d %d" % (num, off))
+            bodies.append(body)
+            off += len(body)
+        h = b" ".join(head) + b"\n"
+        raw = zlib.compress(h + b"".join(bodies))
+        out += b"90 0 obj\n<< /Type /ObjStm /N %d /First %d /Length %d /Filter /FlateDecode >>\nstream\n" % (len(compressed), len(h), len(raw)) + raw + b"\nendstream\nendobj\n"
+    out += b"trailer\n<< /Root 1 0 R >>\n%%EOF\n"
+    return bytes(out)
+
+
+def test_pdf_rasteriser_scanned_pages_like_the_reference(tmp_path):
+    """reference dots_ocr/utils/doc_utils.py:20-60 (PyMuPDF): 200 dpi render, > 4500 px falls back to 72 dpi, page range selection.
+    PyMuPDF is absent here, so the built-in reader renders image-only (scanned) PDFs: a 3-page JPEG PDF written by Pillow, a
+    hand-built PDF 1.5 (object stream, Flate + PNG-predictor RGB image placed with a cm matrix on a larger page, invisible OCR text
+    layer), the oversize fallback, and the refusal of pages it cannot render faithfully."""
+    import zlib
+    from PIL import Image, ImageDraw
+    from dots_ocr_amd import doc_utils as du
+    from dots_ocr.utils.doc_utils import load_images_from_pdf as ref_name_load            # the drop-in import path
+    assert ref_name_load is du.load_images_from_pdf
+
+    def page(i, size=(1654, 2339)):
+        im = Image.new("RGB", size, (255, 255, 255))
+        d = ImageDraw.Draw(im)
+        for y in range(60, size[1] - 60, 90):
+            d.text((80, y), f"page {i} line {y}: the quick brown fox", fill=(0, 0, 0))
+        d.rectangle([100, 100, 300 + 80 * i, 220], outline=(200, 0, 0), width=6)
+        return im
+    pages = [page(i) for i in range(3)]
+    f = tmp_path / "scan.pdf"
+    pages[0].save(f, "PDF", resolution=200.0, save_all=True, append_images=pages[1:])
+    got = du.load_images_from_pdf(str(f))
+    assert [g.size for g in got] == [(1654, 2339)] * 3 and all(g.mode == "RGB" for g in got)
+    for a, b in zip(pages, got):                              # JPEG inside: close, not equal
+        assert np.abs(np.asarray(a, np.int16) - np.asarray(b, np.int16)).mean() < 1.0
+    assert [g.size for g in du.load_images_from_pdf(str(f), start_page_id=1, end_page_id=9)] == [(1654, 2339)] * 2
+    assert len(du.load_images_from_pdf(str(f), start_page_id=2)) == 1 and len(du.load_images_from_pdf(str(f), end_page_id=0)) == 1
+    assert du.load_images_from_pdf(str(f), dpi=72)[0].size == (596, 843)                  # ceil(595.44), ceil(842.04)
+
+    # hand-built: 300 x 200 RGB gradient, Flate + PNG "Up" predictor, drawn at (50, 80) size 300 x 200 pt on a 400 x 400 pt page
+    w, h = 300, 200
+    img = np.zeros((h, w, 3), np.uint8)
+    img[..., 0] = np.arange(w)[None, :] % 256
+    img[..., 1] = (np.arange(h)[:, None] * 255 // (h - 1)).astype(np.uint8)
+    img[..., 2] = 77
+    rows, prev = bytearray(), np.zeros((w * 3,), np.uint8)
+    for r in range(h):
+        cur = img[r].reshape(-1)
+        rows += bytes([2]) + ((cur.astype(np.int16) - prev.astype(np.int16)) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    raw = zlib.compress(bytes(rows))
+    content = b"q 300 0 0 200 50 80 cm /Im0 Do Q BT 3 Tr /F1 12 Tf (hidden ocr layer) Tj ET"
+    objs = {
+        1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+        2: (b"<< /Type /Pages /Kids [3 0 R] /Count 1 /MediaBox [0 0 400 400] >>", None),
+        3: (b"<< /Type /Page /Parent 2 0 R /Resources << /XObject << /Im0 4 0 R >> >> /Contents 5 0 R >>", None),
+        4: (b"<< /Type /XObject /Subtype /Image /Width 300 /Height 200 /ColorSpace /DeviceRGB /BitsPerComponent 8 /Filter /FlateDecode "
+            b"/DecodeParms << /Predictor 15 /Colors 3 /BitsPerComponent 8 /Columns 300 >> /Length %d >>" % len(raw), raw),
+        5: (b"<< /Length %d >>" % len(content), content),
+    }
+    data = _pdf(objs, compressed=(1, 2, 3))
+    doc = du.PdfDocument(data)
+    assert doc.page_count == 1
+    out = np.asarray(du.fitz_doc_to_image(doc[0], target_dpi=72))                          # 1 pt = 1 px: no resampling
+    assert out.shape == (400, 400, 3)
+    assert np.array_equal(out[400 - 80 - 200:400 - 80, 50:350], img)                       # PDF y axis points up
+    assert (out[:120] == 255).all() and (out[:, :50] == 255).all() and (out[:, 350:] == 255).all() and (out[320:] == 255).all()
+    big = np.asarray(du.fitz_doc_to_image(doc[0], target_dpi=200))
+    assert big.shape == (1112, 1112, 3) and tuple(big[1111 - 300, 300]) != (255, 255, 255) and tuple(big[5, 5]) == (255, 255, 255)
+
+    # > 4500 px at the target dpi -> 72 dpi (reference doc_utils.py:33-36)
+    objs[2] = (b"<< /Type /Pages /Kids [3 0 R] /Count 1 /MediaBox [0 0 2000 1700] >>", None)
+    assert du.fitz_doc_to_image(du.PdfDocument(_pdf(objs))[0], target_dpi=200).size == (2000, 1700)
+
+    # visible text / vector painting: refused, not rendered wrongly
+    for bad in (b"BT /F1 12 Tf (visible) Tj ET", b"0 0 100 100 re f"):
+        objs[5] = (b"<< /Length %d >>" % len(bad), bad)
+        with pytest.raises(du.PdfContentNotSupported):
+            du.fitz_doc_to_image(du.PdfDocument(_pdf(objs))[0])
