@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--workload", default="a4", choices=["a4", "highres", "tiny", "mixed64", "svg"])
     ap.add_argument("--fp8", type=int, default=None, help="1: e4m3 per-channel weights (DotsConfig.fp8_weights); default: on for --workload svg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="strictly sequential batches (ViT -> prefill -> decode); default: the tower of batch k+1 runs on a CU-masked side stream "
+                         "while batch k decodes on the complementary CU partition (dots_vit_prefetch)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -248,17 +251,34 @@ def main():
         body = (body + rng.integers(0, 200, len(body))) % 256      # still byte ids
         return np.concatenate([h_ids, [cfg.image_token_id] * n_vis, t_ids[:1], body, t_ids[-2:]]).astype(np.int32)
 
-    def step():
-        t0 = time.perf_counter()
-        prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
-        t1 = time.perf_counter()
+    overlap = not a.no_overlap and not mixed
+
+    def preprocess_all():
         grids, off = [], 0
         for dptr, arr, n in zip(page_dev, page_arrays, n_patches):
             grids.append(eng.preprocess_image(dptr, pix_dev + off * v.patch_dim * 4, shape=arr.shape[:2]))
             off += n
+        return grids
+
+    def step(pipelined=False):
+        """One batch: tokenise, GPU preprocessing, tower, prefill, greedy decode, detokenise.  pipelined: the tower rows of THIS batch were
+        prefetched during the previous step and are taken now; the preprocessing + tower launched here are those of the NEXT batch and
+        run on the CU-masked side stream while this batch's decode loop runs on the other CU partition.  Per step the same work either
+        way: one preprocessing pass, one tower, one prefill, one decode loop."""
+        t0 = time.perf_counter()
+        prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
+        t1 = time.perf_counter()
+        if pipelined:
+            eng.vit_take()
+        grids = preprocess_all()
         t2 = time.perf_counter()
         grid = np.asarray(grids, np.int64)
-        if mixed:
+        if pipelined:
+            eng.vit_prefetch(pix_dev, grid, on_device=True, after_prefill=True)        # starts behind this batch's prefill
+            ids = np.concatenate(prompts)
+            lens = np.asarray([len(p) for p in prompts], np.int32)
+            out, out_lens = eng.generate(ids, lens, max_new_tokens=a.max_new_tokens, eos_ids=(), vision_taken=True)
+        elif mixed:
             from dots_ocr_amd.scheduler import ContinuousBatcher, Request
             reqs, off = [], 0
             for pr, g, n in zip(prompts, grids, n_patches):
@@ -281,8 +301,15 @@ def main():
         host_ms["detokenize_ms"] += (t4 - t3) * 1e3
         return out, out_lens, texts, prompts
 
-    for _ in range(a.warmup):
+    seq_stats = None
+    if overlap:
+        # one strictly sequential batch first: warms everything up AND gives the per-kernel whole-chip timings of this very run
+        # (reported beside the timed region's, where the tower and the decode loop share the chip); then the pipeline is primed
         step()
+        seq_stats = eng.stats()
+        eng.vit_prefetch(pix_dev, np.asarray(preprocess_all(), np.int64), on_device=True)
+    for _ in range(a.warmup):
+        step(overlap)
     for k in host_ms:
         host_ms[k] = 0.0
     eng.synchronize(); torch.cuda.synchronize(); barrier()
@@ -290,7 +317,7 @@ def main():
     phase = {"vit_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "vit_attn_ms": 0.0}
     last = None
     for _ in range(a.steps):
-        out, out_lens, texts, prompts = step()
+        out, out_lens, texts, prompts = step(overlap)
         st = eng.stats()                             # device-side HIP-event times of this step (static batches only)
         for k in phase:
             phase[k] += st[k]
@@ -342,32 +369,62 @@ def main():
             res["config"] = {"workload": f"{a.workload}: {B} pages/GPU of {size[0]}x{size[1]} px -> {n_patches[0]} patches, "
                                          f"{len(prompts[0])} prompt tokens/page, max_new_tokens={a.max_new_tokens}, EOS disabled",
                              "pages_per_gpu": B, "parallelism": f"dp{world}"}
-            attn_s, dec_s, vit_s = phase["vit_attn_ms"] / 1e3, phase["decode_ms"] / 1e3, phase["vit_ms"] / 1e3
-            attn_tflops = last["vit_attn_flops"] * K / attn_s / 1e12 if attn_s > 0 else 0.0
-            dec_gbs = last["decode_bytes"] * K / dec_s / 1e9 if dec_s > 0 else 0.0
-
             def recorded(name, key):            # PMC numbers come from separate rocprofv3 --pmc passes over this same command
                 f = ROOT / "profiles" / name
                 if a.workload == "a4" and B == 8 and f.exists():
                     return json.loads(f.read_text()).get(key)
                 return None
-            res["decode_tok_s"] = int(out_lens.sum()) * K / dec_s if dec_s > 0 else None
+
+            def rooflines(ph, n, lastst, cus_vit, cus_dec):
+                """roofline objects from per-phase HIP-event sums `ph` over `n` steps.  `frac` is ALWAYS against the whole chip's peak; when the
+                kernel ran on a CU partition (overlapped mode) its share of the chip is stated and the fraction of that share's peak added."""
+                attn_s, dec_s, vit_s = ph["vit_attn_ms"] / 1e3, ph["decode_ms"] / 1e3, ph["vit_ms"] / 1e3
+                attn_tflops = lastst["vit_attn_flops"] * n / attn_s / 1e12 if attn_s > 0 else 0.0
+                dec_gbs = lastst["decode_bytes"] * n / dec_s / 1e9 if dec_s > 0 else 0.0
+                vit_tflops = lastst["vit_flops"] * n / vit_s / 1e12 if vit_s > 0 else 0.0
+                r = {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
+                     "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tflops / PEAK_BF16_TFLOPS,
+                     "traffic": recorded("r03_flash_attn_traffic.json", "traffic_bytes_per_launch"),
+                     "traffic_unit": "bytes/launch (PMC on the whole chip, profiles/r03_flash_attn_traffic.json)",
+                     "algorithmic_flops_per_launch": lastst["vit_attn_flops"] / max(1, lastst["vit_attn_launches"]),
+                     "launches_per_step": lastst["vit_attn_launches"],
+                     "avg_launch_ms": ph["vit_attn_ms"] / n / max(1, lastst["vit_attn_launches"])}
+                rv = {"bound": "mfma", "achieved": vit_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": vit_tflops / PEAK_BF16_TFLOPS}
+                rd = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS,
+                      "ms_per_decode_step": ph["decode_ms"] / n / max(1, lastst["decode_steps"]),
+                      "algorithmic_bytes_per_decode_step": lastst["decode_bytes"] / max(1, lastst["decode_steps"]),
+                      "traffic": recorded("r03_decode_traffic.json", "traffic_bytes_per_decode_step"),
+                      "traffic_unit": "bytes per decode step (PMC on the whole chip, profiles/r03_decode_traffic.json)"}
+                if cus_vit < 256:
+                    for o in (r, rv):
+                        o["cus"] = cus_vit
+                        o["frac_of_partition_peak"] = o["frac"] * 256.0 / cus_vit
+                    rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
+                return r, rv, rd
+            dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
+            cv, cd = (256 - dec_cus, dec_cus) if overlap else (256, 256)
+            res["roofline"], res["roofline_vit"], res["roofline_decode"] = rooflines(phase, K, last, cv, cd)
+            res["decode_tok_s"] = int(out_lens.sum()) * K / (phase["decode_ms"] / 1e3) if phase["decode_ms"] > 0 else None
             res["phase_ms_per_step"] = {**{k: val / K for k, val in phase.items()}, **{k: val / K for k, val in host_ms.items()}}
-            res["roofline"] = {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
-                               "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tflops / PEAK_BF16_TFLOPS,
-                               "traffic": recorded("r01_flash_attn_traffic.json", "traffic_bytes_per_launch"),
-                               "traffic_unit": "bytes/launch (PMC, profiles/r01_flash_attn_traffic.json)",
-                               "algorithmic_flops_per_launch": last["vit_attn_flops"] / max(1, last["vit_attn_launches"]),
-                               "launches_per_step": last["vit_attn_launches"],
-                               "avg_launch_ms": phase["vit_attn_ms"] / K / max(1, last["vit_attn_launches"])}
-            res["roofline_vit"] = {"bound": "mfma", "achieved": last["vit_flops"] * K / vit_s / 1e12 if vit_s > 0 else 0.0,
-                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": (last["vit_flops"] * K / vit_s / 1e12 / PEAK_BF16_TFLOPS) if vit_s > 0 else 0.0}
-            res["roofline_decode"] = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS,
-                                      "ms_per_decode_step": phase["decode_ms"] / K / max(1, last["decode_steps"]),
-                                      "algorithmic_bytes_per_decode_step": last["decode_bytes"] / max(1, last["decode_steps"]),
-                                      "traffic": recorded("r02_decode_traffic.json", "traffic_bytes_per_decode_step"),
-                                      "traffic_unit": "bytes per decode step (PMC, profiles/r02_decode_traffic.json)"}
+            if overlap:
+                res["overlap"] = {
+                    "mode": "software-pipelined batches: the vision tower of batch k+1 (stream masked to CUs %d-255, an equal share of every XCD) runs "
+                            "while batch k is prefilled and decoded (decode graph on the stream masked to CUs 0-%d until the tower is done, whole chip "
+                            "after); per step exactly one preprocessing pass, one tower, one prefill, one decode loop; phase_ms_per_step therefore "
+                            "OVERLAP and sum to more than ms_per_step" % (dec_cus, dec_cus - 1),
+                    "dec_cus": dec_cus, "vit_cus": 256 - dec_cus,
+                    "sequential_step_ms_same_run": seq_stats["total_ms"] if seq_stats else None,
+                    "why": "two unmasked streams time-slice the chip (measured: no overlap); with complementary CU masks the MFMA-bound tower and the "
+                           "latency-bound decode loop run side by side (tools/overlap_probe.py, profiles/r03_overlap_probe.txt)"}
+                # the same kernels alone on the whole chip: the strictly sequential batch this run started with (1 step: 42 attention launches, 1023 decode steps)
+                seq_phase = {k: seq_stats[k] for k in phase}
+                rs, rvs, rds = rooflines(seq_phase, 1, seq_stats, 256, 256)
+                res["roofline_sequential"], res["roofline_vit_sequential"], res["roofline_decode_sequential"] = rs, rvs, rds
+                step_s = dt / K
+                res["roofline_step"] = {"note": "sustained over the WHOLE step (all phases, overlapped or not): algorithmic ViT+prefill flops / step time vs the "
+                                                "dense bf16 peak, and algorithmic decode bytes / step time vs the HBM peak",
+                                        "mfma_frac": (last["vit_flops"] + last["prefill_flops"]) / step_s / 1e12 / PEAK_BF16_TFLOPS,
+                                        "hbm_frac": last["decode_bytes"] / step_s / 1e9 / PEAK_HBM_GBS}
             if a.workload == "svg":                 # 4096 decode steps at B = 1 dominate this configuration: its roofline is the HBM one
                 res["roofline_vit_attn"] = res["roofline"]
                 res["roofline"] = {**res["roofline_decode"], "kernel": "one decode step (dec_qkv / decode_attn / combine / dec_proj / dec_gateup x 28 + dec_lmhead)"}

@@ -117,6 +117,22 @@ struct DotsEngine {
     // fp8 mode: per-token quantised activations of the GEMM being launched (max rows x max K bytes) + their scales
     uint8_t* act_q = nullptr;
     float* act_s = nullptr;
+    uint8_t* act_q_v = nullptr;            // the vision tower's own quantisation scratch (it may run beside a prefill: dots_vit_prefetch)
+    float* act_s_v = nullptr;
+    // ---- vision prefetch (dots_vit_prefetch): the tower of the NEXT page batch runs on `s_vit`, a stream masked to the upper
+    // 256 - dec_cus CUs (an equal share of every XCD), while the decode loop of the current batch is replayed on `s_dec`, masked to
+    // the lower dec_cus CUs.  Without the masks the two streams time-slice the chip and nothing overlaps (tools/overlap_probe.py).
+    hipStream_t s_vit = nullptr, s_dec = nullptr;
+    int dec_cus = 128;
+    hipEvent_t ev_vis_ready = nullptr, ev_xs = nullptr;     // tower finished / cross-stream ordering
+    bf16_t* vis_pref = nullptr;            // merged vision rows of the prefetched batch (swapped with `vis` when taken)
+    int64_t vis_pref_rows = 0;
+    bool pref_pending = false;             // a prefetch was requested and not yet taken
+    bool pref_deferred = false;            // ... and its tower is still to be launched (behind the next prefill)
+    const float* pref_pix = nullptr;       // deferred request
+    int64_t pref_patches = 0;
+    std::vector<int64_t> pref_grid;
+    hipStream_t vs = nullptr;              // the stream vit_forward is currently enqueuing to (stream or s_vit)
     std::vector<LLayer> ll;
     float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
 
@@ -285,15 +301,25 @@ int quantize(DotsEngine* e, bf16_t* W, float** scale, int64_t N, int K, uint8_t*
 }
 
 // One dense layer of ViT / prefill: bf16 MFMA GEMM, or in fp8 mode per-token activation quantisation + the fp8 MFMA GEMM.
-int dense(DotsEngine* e, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale, const bf16_t* bias, const bf16_t* R, void* C,
-          int64_t M, int N, int K, int ldc, int epi) {
+int dense_on(DotsEngine* e, hipStream_t st, uint8_t* aq, float* as, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale,
+             const bf16_t* bias, const bf16_t* R, void* C, int64_t M, int N, int K, int ldc, int epi) {
     if (!W8) {
-        CK(launch_gemm(e->stream, A, W, bias, R, C, M, N, K, K, ldc, epi, wscale));
+        CK(launch_gemm(st, A, W, bias, R, C, M, N, K, K, ldc, epi, wscale));
         return DOTS_OK;
     }
-    CK(launch_quant_act_fp8(e->stream, A, e->act_q, e->act_s, M, K, K));
-    CK(launch_gemm_fp8(e->stream, e->act_q, e->act_s, W8, wscale, bias, R, C, M, N, K, ldc, epi));
+    CK(launch_quant_act_fp8(st, A, aq, as, M, K, K));
+    CK(launch_gemm_fp8(st, aq, as, W8, wscale, bias, R, C, M, N, K, ldc, epi));
     return DOTS_OK;
+}
+// LM prefill: the engine's main stream
+int dense(DotsEngine* e, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale, const bf16_t* bias, const bf16_t* R, void* C,
+          int64_t M, int N, int K, int ldc, int epi) {
+    return dense_on(e, e->stream, e->act_q, e->act_s, A, W, W8, wscale, bias, R, C, M, N, K, ldc, epi);
+}
+// vision tower: whichever stream vit_forward runs on, its own scratch
+int vdense(DotsEngine* e, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale, const bf16_t* bias, const bf16_t* R, void* C,
+           int64_t M, int N, int K, int ldc, int epi) {
+    return dense_on(e, e->vs, e->act_q_v, e->act_s_v, A, W, W8, wscale, bias, R, C, M, N, K, ldc, epi);
 }
 
 // decode copy of a (quantised) row-major matrix: bf16 fragments, or e4m3 fragments in fp8 mode
@@ -463,8 +489,10 @@ int alloc_workspaces(DotsEngine* e) {
     if (c.fp8_weights) {
         const size_t v_max = (size_t)e->P * std::max(E, c.v_intermediate);          // the merger's inputs are [P / g][E g]: P E bytes as well
         const size_t p_max = (size_t)c.max_prefill_tokens * std::max(H, std::max(Nq, c.intermediate_size));
-        CK(e->alloc(&e->act_q, std::max(v_max, p_max)));
-        CK(e->alloc(&e->act_s, (size_t)std::max<int64_t>(e->P, c.max_prefill_tokens)));
+        CK(e->alloc(&e->act_q, p_max));
+        CK(e->alloc(&e->act_s, (size_t)c.max_prefill_tokens));
+        CK(e->alloc(&e->act_q_v, v_max));
+        CK(e->alloc(&e->act_s_v, (size_t)e->P));
     }
     CK(e->alloc(&e->v_xa, (size_t)e->P * kpad));
     CK(e->alloc(&e->v_x, (size_t)e->P * E));
@@ -477,6 +505,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->v_act, (size_t)e->P * c.v_intermediate));
     CK(e->alloc(&e->v_mh, (size_t)(e->P / 4 + 1) * Mg));
     CK(e->alloc(&e->vis, (size_t)(e->P / 4 + 1) * H));
+    CK(e->alloc(&e->vis_pref, (size_t)(e->P / 4 + 1) * H));
     CK(e->alloc(&e->v_cs, (size_t)e->P * 64));
     CK(e->alloc(&e->v_pos, (size_t)e->P * 2));
     CK(e->alloc(&e->v_tiles, (size_t)(e->P / 64 + 256)));
@@ -613,12 +642,13 @@ hipError_t attn_event(DotsEngine* e, int idx) {
         if (r != hipSuccess) return r;
         e->attn_ev.push_back(ev);
     }
-    return hipEventRecord(e->attn_ev[idx], e->stream);
+    return hipEventRecord(e->attn_ev[idx], e->vs);
 }
 
-int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* grid, int n_img, void* out_dev) {
+// Runs on e->vs (the main stream, or s_vit for a prefetch); the merged rows go to `vis_out`.
+int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* grid, int n_img, void* out_dev, bf16_t* vis_out, int64_t* rows_out) {
     const DotsConfig& c = e->cfg;
-    hipStream_t s = e->stream;
+    hipStream_t s = e->vs;
     const int E = c.v_embed_dim, Hh = c.v_heads, m = c.v_merge;
     if (N > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches %lld > max_patches %lld", (long long)N, (long long)e->P);
     if (c.v_temporal_patch != 1) return e->fail(DOTS_E_INVALID, "temporal_patch_size != 1 is not supported");
@@ -662,16 +692,16 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = e->vl[i];
         CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
-        RET(dense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
+        RET(vdense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
         CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
         CK(attn_event(e, 2 * i));
         CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale));
         CK(attn_event(e, 2 * i + 1));
         e->attn_pairs = i + 1;
-        RET(dense(e, e->v_att, L.proj_w, L.proj_8, L.proj_s, L.proj_b, e->v_x, e->v_x, N, E, E, E, EPI_RESIDUAL));
+        RET(vdense(e, e->v_att, L.proj_w, L.proj_8, L.proj_s, L.proj_b, e->v_x, e->v_x, N, E, E, E, EPI_RESIDUAL));
         CK(launch_rmsnorm(s, e->v_x, L.norm2, e->v_xn, N, E, c.v_rms_eps));
-        RET(dense(e, e->v_xn, L.w13, L.w13_8, L.w13_s, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, c.v_intermediate, EPI_SWIGLU));
-        RET(dense(e, e->v_act, L.w2, L.w2_8, L.w2_s, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, E, EPI_RESIDUAL));
+        RET(vdense(e, e->v_xn, L.w13, L.w13_8, L.w13_s, L.b13, nullptr, e->v_act, N, 2 * c.v_intermediate, E, c.v_intermediate, EPI_SWIGLU));
+        RET(vdense(e, e->v_act, L.w2, L.w2_8, L.w2_s, L.b2, e->v_x, e->v_x, N, E, c.v_intermediate, E, EPI_RESIDUAL));
         if (e->dbg_hidden && (size_t)(i + 1) * N * E <= e->dbg_cap) {
             CK(hipMemcpyAsync(e->dbg_hidden + (size_t)i * N * E, e->v_x, (size_t)N * E * 2, hipMemcpyDeviceToDevice, s));
             e->dbg_vit_rows = N;
@@ -685,11 +715,11 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     CK(launch_layernorm(s, xin, e->m_ln_w, e->m_ln_b, e->v_att, N, E, c.v_ln_eps));
     const int g = m * m, Mg = E * g;
     const int64_t R = N / g;
-    RET(dense(e, e->v_att, e->m0_w, e->m0_8, e->m0_s, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, EPI_GELU));
-    RET(dense(e, e->v_mh, e->m2_w, e->m2_8, e->m2_s, e->m2_b, nullptr, e->vis, R, c.hidden_size, Mg, c.hidden_size, EPI_NONE));
+    RET(vdense(e, e->v_att, e->m0_w, e->m0_8, e->m0_s, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, EPI_GELU));
+    RET(vdense(e, e->v_mh, e->m2_w, e->m2_8, e->m2_s, e->m2_b, nullptr, vis_out, R, c.hidden_size, Mg, c.hidden_size, EPI_NONE));
     CK(hipEventRecord(e->ev[1], s));
-    e->vis_rows = R;
-    if (out_dev) CK(hipMemcpyAsync(out_dev, e->vis, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
+    *rows_out = R;
+    if (out_dev) CK(hipMemcpyAsync(out_dev, vis_out, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
 
     // algorithmic flops
     e->stats.vit_patches = N;
@@ -721,6 +751,62 @@ void drop_step_graphs(DotsEngine* e) {
         hipGraphDestroy(g.graph);
     }
     e->step_graphs.clear();
+}
+
+// CU-masked side streams of the vision prefetch, created on first use.  Mask bit i = CU i / 8 of XCD i % 8 (profiles/r01_probe_cu_mask.txt):
+// bits [0, dec_cus) for the decode loop, [dec_cus, 256) for the tower — each an equal share of every XCD.
+int ensure_overlap_streams(DotsEngine* e) {
+    if (e->s_vit) return DOTS_OK;
+    if (const char* v = getenv("DOTS_OCR_OVERLAP_DEC_CUS")) e->dec_cus = std::max(32, std::min(224, atoi(v) / 8 * 8));
+    uint32_t wd[8] = {0}, wv[8] = {0};
+    for (int b = 0; b < 256; ++b) (b < e->dec_cus ? wd : wv)[b / 32] |= 1u << (b % 32);
+    CK(hipExtStreamCreateWithCUMask(&e->s_dec, 8, wd));
+    CK(hipExtStreamCreateWithCUMask(&e->s_vit, 8, wv));
+    CK(hipEventCreateWithFlags(&e->ev_vis_ready, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&e->ev_xs, hipEventDisableTiming));
+    return DOTS_OK;
+}
+
+// make `to` wait for everything enqueued on `from` so far
+int chain_streams(DotsEngine* e, hipStream_t from, hipStream_t to) {
+    if (from == to) return DOTS_OK;
+    CK(hipEventRecord(e->ev_xs, from));
+    CK(hipStreamWaitEvent(to, e->ev_xs, 0));
+    return DOTS_OK;
+}
+
+// The stream the next decode chunk should be replayed on: the lower CU partition while a prefetched tower is still running (the two then
+// share the chip instead of time-slicing it), the whole chip otherwise.  Hands the dependency over when the stream changes.
+int pick_decode_stream(DotsEngine* e, hipStream_t* cur) {
+    hipStream_t want = e->stream;
+    if (e->s_vit && e->pref_pending && hipEventQuery(e->ev_vis_ready) == hipErrorNotReady) want = e->s_dec;
+    if (want != *cur) {
+        RET(chain_streams(e, *cur, want));
+        *cur = want;
+    }
+    return DOTS_OK;
+}
+
+int stage_pixels(DotsEngine* e, hipStream_t st, const float* pixel_values, int on_device, int64_t total_patches, const float** pix) {
+    *pix = pixel_values;
+    if (!on_device) {
+        if (total_patches > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches exceeds max_patches");
+        if (!e->v_pix) CK(e->alloc(&e->v_pix, (size_t)e->P * e->patch_k));
+        CK(hipMemcpyAsync(e->v_pix, pixel_values, (size_t)total_patches * e->patch_k * 4, hipMemcpyHostToDevice, st));
+        *pix = e->v_pix;
+    }
+    return DOTS_OK;
+}
+
+// the tower of the prefetch request, on the side stream, behind everything the main stream holds so far
+int launch_prefetched_tower(DotsEngine* e) {
+    e->pref_deferred = false;
+    RET(chain_streams(e, e->stream, e->s_vit));          // the pixels (dots_preprocess_image), an earlier tower pass, the prefill it was deferred behind
+    e->vs = e->s_vit;
+    int r = vit_forward(e, e->pref_pix, e->pref_patches, e->pref_grid.data(), (int)(e->pref_grid.size() / 3), nullptr, e->vis_pref, &e->vis_pref_rows);
+    e->vs = e->stream;
+    CK(hipEventRecord(e->ev_vis_ready, e->s_vit));
+    return r;
 }
 
 // Prefill B packed prompts.  slots == nullptr: the static batch (sequence b -> slot b, every slot reset).
@@ -866,6 +952,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         e->h_prompt_lens = L;
     }
     page_guard.armed = false;
+    if (e->pref_deferred) RET(launch_prefetched_tower(e));          // the next batch's tower starts behind this prefill (dots_vit_prefetch, after_prefill)
     e->steps_done = 0;
     e->vis_rows = 0;
     e->stats.prefill_tokens = T;
@@ -1037,6 +1124,14 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
     DotsEngine* e = new DotsEngine();
     e->cfg = c;
     e->device = device;
+    // DOTS_OCR_CU_RANGE="lo-hi" (experiment, tools/overlap_probe.py): the engine's stream only uses CU-mask bits lo..hi (of 256; bit i = CU i / 8 of XCD i % 8)
+    if (const char* cr = getenv("DOTS_OCR_CU_RANGE")) {
+        int lo = 0, hi = 255;
+        if (sscanf(cr, "%d-%d", &lo, &hi) != 2 || lo < 0 || hi > 255 || lo > hi) { g_create_error = "bad DOTS_OCR_CU_RANGE"; delete e; return DOTS_E_INVALID; }
+        uint32_t words[8] = {0};
+        for (int b = lo; b <= hi; ++b) words[b / 32] |= 1u << (b % 32);
+        if (hipExtStreamCreateWithCUMask(&e->stream, 8, words) != hipSuccess) { g_create_error = "hipExtStreamCreateWithCUMask failed"; delete e; return DOTS_E_HIP; }
+    } else
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete e; return DOTS_E_HIP; }
     int r = alloc_workspaces(e);
     if (r != DOTS_OK) { g_create_error = e->err; dots_destroy(e); return r; }
@@ -1047,8 +1142,14 @@ int dots_create(const DotsConfig* cfg, int device, DotsEngine** out) {
 void dots_destroy(DotsEngine* e) {
     if (!e) return;
     hipSetDevice(e->device);
+    if (e->s_vit) hipStreamSynchronize(e->s_vit);
+    if (e->s_dec) hipStreamSynchronize(e->s_dec);
     if (e->stream) hipStreamSynchronize(e->stream);
     drop_step_graphs(e);
+    if (e->ev_vis_ready) hipEventDestroy(e->ev_vis_ready);
+    if (e->ev_xs) hipEventDestroy(e->ev_xs);
+    if (e->s_vit) hipStreamDestroy(e->s_vit);
+    if (e->s_dec) hipStreamDestroy(e->s_dec);
     for (void* p : e->allocs) hipFree(p);
     for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
     for (auto& ev : e->attn_ev) hipEventDestroy(ev);
@@ -1095,14 +1196,49 @@ int dots_vit_forward(DotsEngine* e, const float* pixel_values, int on_device, in
     if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
     if (!pixel_values || !grid_thw || n_img < 1 || total_patches < 1) return e->fail(DOTS_E_INVALID, "bad vit_forward arguments");
     CK(hipSetDevice(e->device));
-    const float* pix = pixel_values;
-    if (!on_device) {
-        if (total_patches > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches exceeds max_patches");
-        if (!e->v_pix) CK(e->alloc(&e->v_pix, (size_t)e->P * e->patch_k));
-        CK(hipMemcpyAsync(e->v_pix, pixel_values, (size_t)total_patches * e->patch_k * 4, hipMemcpyHostToDevice, e->stream));
-        pix = e->v_pix;
+    if (e->pref_deferred) RET(launch_prefetched_tower(e));
+    if (e->s_vit) CK(hipStreamWaitEvent(e->stream, e->ev_vis_ready, 0));          // the tower's workspaces: one pass at a time
+    const float* pix = nullptr;
+    RET(stage_pixels(e, e->stream, pixel_values, on_device, total_patches, &pix));
+    e->vs = e->stream;
+    return vit_forward(e, pix, total_patches, grid_thw, n_img, out_embeds_dev, e->vis, &e->vis_rows);
+}
+
+int dots_vit_prefetch(DotsEngine* e, const float* pixel_values, int on_device, int64_t total_patches, const int64_t* grid_thw, int n_img,
+                      int after_prefill) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
+    if (!pixel_values || !grid_thw || n_img < 1 || total_patches < 1) return e->fail(DOTS_E_INVALID, "bad vit_prefetch arguments");
+    if (e->pref_pending) return e->fail(DOTS_E_STATE, "a prefetched vision batch is waiting: dots_vit_take_prefetched first");
+    CK(hipSetDevice(e->device));
+    RET(ensure_overlap_streams(e));
+    const float* pix = nullptr;
+    RET(stage_pixels(e, e->stream, pixel_values, on_device, total_patches, &pix));      // host pixels: staged on the main stream, now
+    e->pref_pix = pix;
+    e->pref_patches = total_patches;
+    e->pref_grid.assign(grid_thw, grid_thw + (size_t)n_img * 3);
+    e->pref_pending = true;
+    e->pref_deferred = true;
+    if (!after_prefill) {
+        int r = launch_prefetched_tower(e);
+        if (r != DOTS_OK) { e->pref_pending = false; return r; }
     }
-    return vit_forward(e, pix, total_patches, grid_thw, n_img, out_embeds_dev);
+    return DOTS_OK;
+}
+
+int dots_vit_take_prefetched(DotsEngine* e) {
+    if (!e) return DOTS_E_INVALID;
+    if (!e->pref_pending) return e->fail(DOTS_E_STATE, "no prefetched vision batch (dots_vit_prefetch)");
+    CK(hipSetDevice(e->device));
+    if (e->pref_deferred) {                              // no prefill came by: run it now
+        int r = launch_prefetched_tower(e);
+        if (r != DOTS_OK) { e->pref_pending = false; return r; }
+    }
+    CK(hipStreamWaitEvent(e->stream, e->ev_vis_ready, 0));
+    std::swap(e->vis, e->vis_pref);
+    e->vis_rows = e->vis_pref_rows;
+    e->pref_pending = false;
+    return DOTS_OK;
 }
 
 int dots_prefill(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt_lens, int B) {
@@ -1139,9 +1275,13 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     for (int b = 0; b < B; ++b) max_prompt = std::max(max_prompt, prompt_lens[b]);
     if (max_prompt + max_new_tokens > e->cfg.max_seq_len)
         return e->fail(DOTS_E_CAPACITY, "prompt (%d) + max_new_tokens (%d) exceeds max_seq_len %d", max_prompt, max_new_tokens, e->cfg.max_seq_len);
-    e->stats = DotsStats{};
+    {   // the tower of a prefetch launched before this call (pipelined batches) keeps its stats; everything else starts from zero
+        const DotsStats keep = e->stats;
+        e->stats = DotsStats{};
+        if (n_img == -1) { e->stats.vit_patches = keep.vit_patches; e->stats.vit_attn_flops = keep.vit_attn_flops; e->stats.vit_flops = keep.vit_flops; }
+    }
     CK(hipEventRecord(e->ev[6], s));
-    e->vis_rows = 0;
+    if (n_img != -1) e->vis_rows = 0;               // n_img == -1: the rows dots_vit_take_prefetched put in place
     if (n_img > 0) RET(dots_vit_forward(e, pixel_values, on_device, total_patches, grid_thw, n_img, nullptr));
     e->n_eos = n_eos;
     if (n_eos) CK(hipMemcpyAsync(e->eos_ids, eos_ids, n_eos * 4, hipMemcpyHostToDevice, s));
@@ -1156,18 +1296,22 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     if (use_graph && max_new_tokens > 1) RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
     std::vector<int32_t> fin(DOTS_MAX_BATCH);
     int steps = 0;
+    hipStream_t cur = s;                           // where the decode graph is replayed: see pick_decode_stream
     for (int step = 1; step < max_new_tokens; ++step) {
-        if (exec) CK(hipGraphLaunch(exec, s));
+        if (exec && (step & 15) == 1) RET(pick_decode_stream(e, &cur));
+        if (exec) CK(hipGraphLaunch(exec, cur));
         else RET(decode_step_launches(e, n_splits));
         ++steps;
         if (n_eos && (step % 16 == 0)) {       // early exit once every sequence hit EOS
-            CK(hipMemcpyAsync(fin.data(), e->finished, B * 4, hipMemcpyDeviceToHost, s));
-            CK(hipStreamSynchronize(s));
+            CK(hipMemcpyAsync(fin.data(), e->finished, B * 4, hipMemcpyDeviceToHost, cur));
+            CK(hipStreamSynchronize(cur));
             bool all = true;
             for (int b = 0; b < B; ++b) all = all && fin[b];
             if (all) break;
         }
+        if (exec && !n_eos && cur != s && (step & 63) == 0) CK(hipStreamSynchronize(cur));     // let the host see the tower finish (the queue is 16 steps deep otherwise)
     }
+    RET(chain_streams(e, cur, s));
     CK(hipEventRecord(e->ev[5], s));
     CK(hipEventRecord(e->ev[7], s));
     e->steps_done = steps;
@@ -1345,6 +1489,7 @@ int dots_get_stats(DotsEngine* e, DotsStats* out) {
     if (!e || !out) return DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
     CK(hipStreamSynchronize(e->stream));
+    if (e->s_vit) CK(hipStreamSynchronize(e->s_vit));        // a prefetched tower's events (the next call would wait for it anyway)
     // An event pair that was never recorded (e.g. the static-batch events after a slot-mode run) makes hipEventElapsedTime fail; the
     // failure must not stay behind as the thread's "last error" (PyTorch / RCCL check hipGetLastError after their own launches).
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) {
@@ -1499,6 +1644,8 @@ int dots_debug_read_hidden(DotsEngine* e, int which, int layer, void* out_host, 
 int dots_synchronize(DotsEngine* e) {
     if (!e) return DOTS_E_INVALID;
     CK(hipSetDevice(e->device));
+    if (e->s_vit) CK(hipStreamSynchronize(e->s_vit));
+    if (e->s_dec) CK(hipStreamSynchronize(e->s_dec));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

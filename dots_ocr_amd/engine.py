@@ -65,6 +65,8 @@ def _prototypes(lib):
         "dots_load_weight": (i32, [vp, C.c_char_p, vp, i32, P(i64), i32]),
         "dots_finalize_weights": (i32, [vp]),
         "dots_vit_forward": (i32, [vp, vp, i32, i64, P(i64), i32, vp]),
+        "dots_vit_prefetch": (i32, [vp, vp, i32, i64, P(i64), i32, i32]),
+        "dots_vit_take_prefetched": (i32, [vp]),
         "dots_prefill": (i32, [vp, P(i32), P(i32), i32]),
         "dots_decode_step": (i32, [vp]),
         "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
@@ -116,7 +118,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_flow", "dots_get_logits",
+    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_flow", "dots_get_logits",
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info", "dots_slot_capacity", "dots_slots_reset",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
@@ -246,6 +248,24 @@ class Engine:
                                            C.c_void_p(out_dev) if out_dev else None), "dots_vit_forward")
         return n // (self.cfg.vision.spatial_merge_size ** 2)
 
+    def vit_prefetch(self, pixel_values, grid_thw: np.ndarray, on_device: bool = False, after_prefill: bool = False) -> int:
+        """The tower of the NEXT page batch, asynchronously on the CU-masked side stream (include/dots_ocr_hip.h "Software
+        pipelining"); pixel_values must stay alive until vit_take().  after_prefill: launch it behind the next prefill."""
+        grid = np.ascontiguousarray(grid_thw, dtype=np.int64)
+        n = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+        if on_device:
+            ptr = C.c_void_p(int(pixel_values))
+        else:
+            self._pref_keep = np.ascontiguousarray(pixel_values, dtype=np.float32)
+            assert self._pref_keep.shape[0] == n, (self._pref_keep.shape, n)
+            ptr = self._pref_keep.ctypes.data_as(C.c_void_p)
+        self._ck(self.lib.dots_vit_prefetch(self.h, ptr, int(on_device), n, _i64p(grid), grid.shape[0], int(after_prefill)), "dots_vit_prefetch")
+        return n // (self.cfg.vision.spatial_merge_size ** 2)
+
+    def vit_take(self):
+        """Put the prefetched vision rows in place for the next prefill / generate(..., vision_taken=True)."""
+        self._ck(self.lib.dots_vit_take_prefetched(self.h), "dots_vit_take_prefetched")
+
     def preprocess_image(self, rgb, out_dev: int, min_pixels: Optional[int] = None, max_pixels: Optional[int] = None,
                          shape: Optional[Sequence[int]] = None):
         """uint8 [h, w, 3] image -> float32 patches written at device pointer `out_dev`; returns [t, gh, gw].
@@ -363,8 +383,9 @@ class Engine:
 
     def generate(self, input_ids: np.ndarray, prompt_lens: np.ndarray, pixel_values=None,
                  grid_thw: Optional[np.ndarray] = None, max_new_tokens: int = 128, eos_ids: Sequence[int] = (),
-                 pixel_on_device: bool = False):
-        """Packed prompts + packed patches -> (out_ids [B, max_new_tokens] int32, out_lens [B])."""
+                 pixel_on_device: bool = False, vision_taken: bool = False):
+        """Packed prompts + packed patches -> (out_ids [B, max_new_tokens] int32, out_lens [B]).
+        vision_taken: the vision rows were prefetched and taken (vit_prefetch / vit_take); pixel_values / grid_thw are ignored."""
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         lens = np.ascontiguousarray(prompt_lens, dtype=np.int32)
         B = int(lens.shape[0])
@@ -372,7 +393,9 @@ class Engine:
         out_ids = np.zeros((B, max_new_tokens), dtype=np.int32)
         out_lens = np.zeros((B,), dtype=np.int32)
         eos = np.ascontiguousarray(list(eos_ids), dtype=np.int32)
-        if grid_thw is not None and len(grid_thw):
+        if vision_taken:
+            ptr, n, gp, n_img = None, 0, None, -1
+        elif grid_thw is not None and len(grid_thw):
             grid = np.ascontiguousarray(grid_thw, dtype=np.int64)
             n = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
             if pixel_on_device:

@@ -174,17 +174,35 @@ class DotsOcrHipForCausalLM:
             for b, o in enumerate(outs):
                 new_tokens[b, :len(o)] = o
                 n_max = max(n_max, len(o))
-        for sl in ([] if continuous else plan_batches(seq_patches, self.max_batch, self.max_patches)):    # static batches within the engine's capacity
+        # static batches within the engine's capacity.  With several batches the vision tower of batch k+1 is prefetched on the engine's
+        # CU-masked side stream while batch k is prefilled and decoded (Engine.vit_prefetch: same tokens, ~20 % more pages/s at 8 x A4).
+        plan = [] if continuous else plan_batches(seq_patches, self.max_batch, self.max_patches)
+
+        def pixels_of(sl):
             imgs = [g for b in sl for g in img_of_seq[b]]
+            if not imgs:
+                return None, None, False
+            lo, hi = int(patch_off[imgs[0]]), int(patch_off[imgs[-1] + 1])         # images of a slice are contiguous
+            g = grid[imgs[0]:imgs[-1] + 1]
+            if pv_dev is not None:
+                return pv_dev.data_ptr() + lo * pv_dev.shape[1] * 4, g, True
+            return pv_host[lo:hi], g, False
+        pipelined = len(plan) > 1 and all(pixels_of(sl)[0] is not None for sl in plan) and hasattr(self.engine, "vit_prefetch")
+        if pipelined:
+            pix, g, on_dev = pixels_of(plan[0])
+            self.engine.vit_prefetch(pix, g, on_device=on_dev)
+        for k, sl in enumerate(plan):
             lens = np.array([len(prompts[b]) for b in sl], np.int32)
             packed = np.concatenate([prompts[b] for b in sl])
-            if imgs:
-                lo, hi = int(patch_off[imgs[0]]), int(patch_off[imgs[-1] + 1])     # images of a slice are contiguous
-                if pv_dev is not None:
-                    pix, on_dev = pv_dev.data_ptr() + lo * pv_dev.shape[1] * 4, True
-                else:
-                    pix, on_dev = pv_host[lo:hi], False
-                out, out_lens = self.engine.generate(packed, lens, pix, grid[imgs[0]:imgs[-1] + 1], max_new_tokens, eos, on_dev)
+            pix, g, on_dev = pixels_of(sl)
+            if pipelined:
+                self.engine.vit_take()
+                if k + 1 < len(plan):
+                    npix, ng, non_dev = pixels_of(plan[k + 1])
+                    self.engine.vit_prefetch(npix, ng, on_device=non_dev, after_prefill=True)
+                out, out_lens = self.engine.generate(packed, lens, max_new_tokens=max_new_tokens, eos_ids=eos, vision_taken=True)
+            elif pix is not None:
+                out, out_lens = self.engine.generate(packed, lens, pix, g, max_new_tokens, eos, on_dev)
             else:
                 out, out_lens = self.engine.generate(packed, lens, None, None, max_new_tokens, eos)
             for j, b in enumerate(sl):

@@ -110,6 +110,21 @@ int dots_vit_forward(DotsEngine* e, const float* pixel_values, int pixel_values_
                      int64_t total_patches, const int64_t* grid_thw_host, int n_img,
                      void* out_embeds_dev);
 
+/* Software pipelining across page batches (no counterpart in the reference's HF path, which is strictly sequential; vLLM overlaps
+ * requests in its scheduler).  dots_vit_prefetch runs the tower of the NEXT batch asynchronously on a side stream that is masked to
+ * the upper (256 - 128) CUs — an equal share of every XCD — and returns at once; while it runs, dots_generate replays its decode
+ * graph on a stream masked to the lower 128 CUs (the two partitions then work side by side: two unmasked streams were measured to
+ * time-slice the chip with no overlap at all), and on the whole chip again once the tower is done.  dots_vit_take_prefetched makes
+ * the main stream wait for the tower and puts its rows in place for the next dots_prefill / dots_slots_prefill, or for
+ * dots_generate with n_img = -1.  Order per batch k: take(k) -> [dots_preprocess_image(k+1)] -> prefetch(k+1) -> generate(k, n_img = -1).
+ * after_prefill != 0: the tower is launched behind the NEXT prefill (dots_prefill / dots_generate / dots_slots_prefill) instead of at once,
+ * so that it shares the chip with the latency-bound decode loop only, not with the MFMA-bound prefill (or at dots_vit_take_prefetched if no
+ * prefill comes by).  pixel_values must stay valid until the rows are taken.  Results are bit-identical to the sequential calls.
+ * Environment DOTS_OCR_OVERLAP_DEC_CUS (multiple of 8, default 128) sets the decode partition. */
+int dots_vit_prefetch(DotsEngine* e, const float* pixel_values, int pixel_values_on_device, int64_t total_patches,
+                      const int64_t* grid_thw_host, int n_img, int after_prefill);
+int dots_vit_take_prefetched(DotsEngine* e);
+
 /* Replaces prepare_inputs_embeds + the prefill forward of Qwen2ForCausalLM.
  * Packed prompts: input_ids int32 [sum(prompt_lens)] (host), slot i of the batch gets prompt i.
  * Vision rows from the preceding dots_vit_forward are scattered at image_token_id positions. */
@@ -121,7 +136,8 @@ int dots_decode_step(DotsEngine* e);
 /* Replaces model.generate(**inputs, max_new_tokens=N) with do_sample=False (parser.py:110):
  * ViT over all images, prefill, greedy decode until every sequence hit an EOS id or N tokens.
  * out_ids int32 [B, max_new_tokens] (host, new tokens only), out_lens int32 [B].
- * n_eos == 0 disables EOS (fixed-length timing runs). */
+ * n_eos == 0 disables EOS (fixed-length timing runs).
+ * n_img == -1: skip the tower, the vision rows are the ones dots_vit_take_prefetched put in place. */
 int dots_generate(DotsEngine* e, const int32_t* input_ids_host, const int32_t* prompt_lens_host, int B,
                   const float* pixel_values, int pixel_values_on_device, int64_t total_patches,
                   const int64_t* grid_thw_host, int n_img, int max_new_tokens,

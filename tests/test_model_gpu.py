@@ -390,6 +390,14 @@ def test_parser_pipelines_a_document_over_the_engine_slots(tmp_path):
         one = parser._parse_single_image(page, "prompt_ocr", str(tmp_path / "single"), "doc", source="pdf", page_idx=i)
         assert Path(one["md_content_path"]).read_text() == Path(piped[i]["md_content_path"]).read_text(), i
         assert (one["input_height"], one["input_width"]) == (piped[i]["input_height"], piped[i]["input_width"])
+    # the same through parse_file on a real .pdf (reference parser.py:263-300: load_images_from_pdf at dpi 200 -> one task per page):
+    # a scanned 3-page document (72-dpi page size 200 x 150 pt -> 556 x 417 px at 200 dpi), rasterised by dots_ocr_amd/doc_utils.py
+    pdf = tmp_path / "scan.pdf"
+    scans = [synth_page(10 + i, (556, 417)) for i in range(3)]
+    scans[0].save(pdf, "PDF", resolution=200.0, save_all=True, append_images=scans[1:])
+    res = parser.parse_file(str(pdf), output_dir=str(tmp_path / "out"), prompt_mode="prompt_ocr")
+    assert [r["page_no"] for r in res] == [0, 1, 2] and all(r["file_path"] == str(pdf) for r in res)
+    assert all(Path(r["md_content_path"]).exists() for r in res) and (tmp_path / "out" / "scan.jsonl").exists()
     model.engine.close()
 
 
