@@ -75,7 +75,7 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
     ViT block costs the same, every LM layer costs the same, every decode step (at fixed context) costs the same.  Timed with a
     FIXED thread count: the tower with 1 and with 3 blocks, the LM prefill with 1 and with 3 layers, 4 decode steps with 1 and
     with 3 layers (per-layer cost = half the difference: two layers' worth of signal instead of the 0-vs-1 difference of round 2);
-    the tower pair is timed twice and the spread reported.  All raw timings are in the record.
+    All raw timings are in the record (the tower pair timed twice differed by 0.9 % in extrapolation: profiles/r03_bench_a4.json).
     Checker code used only as the baseline being reported, never on the product path."""
     import copy
     import torch
@@ -103,7 +103,7 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
     with torch.no_grad():
         om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv[:2048]), torch.tensor([[1, 32, 64]]))       # thread pool / allocator warm-up
         vis = None
-        for _ in range(2):
+        for _ in range(1):                           # (a second pass differed by 0.9 % in the round-3 run: profiles/r03_bench_a4.json; one pass keeps the leg at ~70 s)
             t1, vis = timed(lambda: om.vision_tower(sd, cfg_with(1, 0), torch.from_numpy(pv), grid))
             t3, _ = timed(lambda: om.vision_tower(sd, cfg_with(3, 0), torch.from_numpy(pv), grid))
             raw["vit_1_block_s"].append(t1)
@@ -132,8 +132,7 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
     spread = (max(vit_runs) - min(vit_runs)) / t_vit
     return {"value": 1.0 / t_page, "unit": "pages/s", "cores": cores, "kind": "port",
             "sample": f"fp32 oracle on ONE full synthetic A4 page ({pv.shape[0]} patches, {len(ids)} prompt tokens, {max_new_tokens} new tokens), "
-                      f"{measured:.1f} s measured with {cores} threads: ViT with 1 and 3 of {VL} blocks (twice; the two extrapolations differ by "
-                      f"{spread * 100:.1f} %), LM prefill and {n_dec} decode steps with 1 and 3 of {LL} layers; extrapolated by layer count to "
+                      f"{measured:.1f} s measured with {cores} threads: ViT with 1 and 3 of {VL} blocks" + (f" ({len(vit_runs)} passes; their extrapolations differ by {spread * 100:.1f} %)" if len(vit_runs) > 1 else "") + f", LM prefill and {n_dec} decode steps with 1 and 3 of {LL} layers; extrapolated by layer count to "
                       f"{t_page:.0f} s per page (ViT {t_vit:.0f} s, prefill {t_prefill:.0f} s, decode {t_step * 1e3:.0f} ms/token = {1.0 / t_step:.2f} tok/s)",
             "raw_seconds": {k: ([round(x, 3) for x in v] if isinstance(v, list) else round(v, 4)) for k, v in raw.items()}}
 

@@ -779,7 +779,10 @@ int chain_streams(DotsEngine* e, hipStream_t from, hipStream_t to) {
 // share the chip instead of time-slicing it), the whole chip otherwise.  Hands the dependency over when the stream changes.
 int pick_decode_stream(DotsEngine* e, hipStream_t* cur) {
     hipStream_t want = e->stream;
-    if (e->s_vit && e->pref_pending && hipEventQuery(e->ev_vis_ready) == hipErrorNotReady) want = e->s_dec;
+    if (e->s_vit && e->pref_pending && !e->pref_deferred && hipEventQuery(e->ev_vis_ready) == hipErrorNotReady) {
+        (void)hipGetLastError();                   // "not ready" must not stay behind as the thread's last error (PyTorch / RCCL check it)
+        want = e->s_dec;
+    }
     if (want != *cur) {
         RET(chain_streams(e, *cur, want));
         *cur = want;

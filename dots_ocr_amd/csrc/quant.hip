@@ -1,10 +1,14 @@
 // fp8 weights (BASELINE configs[4] / SURVEY §8(d) config 5): OCP e4m3 ("e4m3fn", gfx950's native fp8) with one fp32
-// scale per OUTPUT channel.  A linear layer y = x W^T then computes, everywhere in this engine,
-//        y[m][n] = ( sum_k x[m][k] * q[n][k] ) * scale[n]          q = e4m3(W[n][k] / scale[n]),  scale[n] = max_k |W[n][k]| / 448
-// with the sum in fp32 on the bf16 MFMA (every e4m3 value is a bf16 value, and x*q is exact in fp32), so the ViT / prefill
-// GEMMs (bf16(q) row-major + a per-column scale in the epilogue) and the decode kernels (q as 1 byte per weight in fragment
-// order, converted to bf16 in registers) produce the same numbers from the same quantised model.  Only decode, the
-// bandwidth-bound phase, streams fp8 bytes; an fp8-MFMA GEMM (2x matrix rate) is not built.
+// scale per OUTPUT channel:  q = e4m3(W[n][k] / scale[n]),  scale[n] = max_k |W[n][k]| / 448.  Two uses of the same quantised model:
+//   * DECODE (bandwidth-bound) is WEIGHT-ONLY (W8A16): the kernels stream q as 1 byte per weight in fragment order, convert it to bf16 in
+//     registers (exact: every e4m3 value is a bf16 value) and multiply bf16 activations on the bf16 MFMA,
+//         y[m][n] = ( sum_k x[m][k] * q[n][k] ) * scale[n]                                           (x bf16, sum in fp32);
+//   * the ViT and PREFILL GEMMs (MFMA-bound) are W8A8: quant_act_fp8 below also quantises the activations per TOKEN (row scale
+//     = max |x[m][:]| / 448, e4m3), gemm_fp8 (gemm.hip) runs on v_mfma_scale_f32_32x32x64_f8f6f4 and its epilogue applies
+//         y[m][n] = ( sum_k xq[m][k] * q[n][k] ) * rowscale[m] * scale[n].
+// So the prefill logits of a token and the decode logits of the same token are NOT the same numbers in fp8 mode: they differ by the
+// activation quantisation (a step function of the activations — see DESIGN §2 for what that does to tolerances:
+// tests/test_fp8_gpu.py compares each phase with the oracle mode that quantises the same things, oracle/model.py fp8_act).
 #include "common.h"
 #include "decode_layout.h"
 #include "kernels.h"
