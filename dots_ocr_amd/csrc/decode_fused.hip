@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restric
 // rows are two complete rotation pairs and the epilogue needs no exchange.  v heads keep the natural order.  Wave 15 owns the
 // epilogue; its operands (position, page id, bias, rotation angles) are fetched / computed while waves < B normalise the rows.
 // k-steps per wave = H / 32 / 16 <= NC (the same bound as the row chunks: H <= 512 NC).
-template <int NC, typename WT>
+// FULL: one whole 16-row tile per workgroup (half as many workgroups: (Hq + 2 Hkv) * 8) — for a stream that is CU-masked to half the chip
+// (the decode partition of the pipelined step, engine.hip), where 256 workgroups of 1024 threads would need two rounds.  Same arithmetic per element.
+template <int NC, typename WT, bool FULL>
 __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                        const WT* __restrict__ Wd, const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
                                                        const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
@@ -73,19 +75,19 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                 // [H/8][XR][8]
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [16 waves][64 lanes]
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1, head = tile >> 3, j = tile & 7;
+    const int half = FULL ? 0 : (blockIdx.y & 1), tile = FULL ? blockIdx.y : (blockIdx.y >> 1), head = tile >> 3, j = tile & 7;
     const int KS = H / 32;
     const int k0 = wv * KS / 16, k1 = (wv + 1) * KS / 16;
     const int m = lane & 15, g = lane >> 4;
     const bool rot = head < Hq + Hkv;
-    const bool epi = wv == 15 && m < B && g < 2;         // accumulator rows 4g + r, g < 2: the 8 rows of this half
+    const bool epi = wv == 15 && m < B && (FULL || g < 2);         // accumulator rows 4g + r, g < 2: the 8 rows of this half
     TRACE(0);
     // ---- 1. small operands (one round trip)
     Rows<1, NC> R;
     rows_issue<1, NC>(R, h, ln_w, B, H, wv, 16, lane);
     // accumulator rows 4g .. 4g+3 of this lane (g < 2): q / k heads (d, d + 64, d + 1, d + 65) with d = 8j + 4 half + 2g;
     // v heads f .. f + 3 with f = 16j + 8 half + 4g
-    const int gg = g & 1;
+    const int gg = FULL ? g : (g & 1);
     const int f0 = rot ? 8 * j + 4 * half + 2 * gg : 16 * j + 8 * half + 4 * gg;          // first feature (even)
     const int f1 = rot ? f0 + 64 : f0 + 2;                                                // second bf16 pair
     const int mc = min(m, B - 1);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- 2. weight slice: lane (g, i) reads row (i & 7) + 8 half of the chunk; rows of the other half are duplicates
-    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, FULL ? m : (m & 7) + 8 * half);
     WT a[NC];
     weights_issue<NC>(a, wp, k0, k1, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
 #ifndef PROJ_G_FP8
 #define PROJ_G_FP8 6
 #endif
-template <int G, typename WT>
+template <int G, typename WT, bool FULL = false>
 __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
                                                         bf16_t* __restrict__ h, int B, int N, int K, int XR) {
     __shared__ f32x4 red[16 * 64];
@@ -178,19 +180,20 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
         X += (size_t)t0 * K; h += (size_t)t0 * N; B = min(16, B - t0);
     }
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1;
+    const int half = FULL ? 0 : (blockIdx.y & 1), tile = FULL ? blockIdx.y : (blockIdx.y >> 1);
     const int KS = K / 32;
     const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);
     const int m = lane & 15, g = lane >> 4;
-    const bool epi = wv == 15 && m < B && g < 2;
-    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
+    const bool epi = wv == 15 && m < B && (FULL || g < 2);
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, FULL ? m : (m & 7) + 8 * half);
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(X) + g * XR + (m & (XR - 1));
     const int xstride = 4 * XR;
-    bf16_t* hp = h + (size_t)min(m, B - 1) * N + tile * 16 + 8 * half + 4 * (g & 1);
+    const int col0 = tile * 16 + (FULL ? 4 * g : 8 * half + 4 * (g & 1));
+    bf16_t* hp = h + (size_t)min(m, B - 1) * N + col0;
     TRACE(0);
     const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + tile * 16 + 8 * half + 4 * (g & 1));
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + col0);
     WT a[G];
     bf16x8 b[G];
 #pragma unroll
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
 // 128-B lines again as the weights (a row-0-only gather for B = 1 was tried: same number of lines, slower).
 // LDS: X image 16 K bytes | reduction buffer 16 KiB  (159 744 B at K = 8960: one workgroup per CU; the grid is N / 8 = 192).
 constexpr int PROJ_LDS_G = 18;
-template <typename WT>
+template <typename WT, bool FULL = false>
 __global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
                                                             bf16_t* __restrict__ h, int B, int N, int K) {
     constexpr int G = PROJ_LDS_G, NP = G / 2 + 1, XR = 8;
@@ -254,17 +257,18 @@ __global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __rest
     char* ximg = smem;                                                            // [K/8][8][8] bf16 = 16 K bytes
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)16 * K);
     const int lane = threadIdx.x & 63, wv = wave_id();
-    const int half = blockIdx.y & 1, tile = blockIdx.y >> 1;                      // B <= 8: a single batch tile (blockIdx.x == 0)
+    const int half = FULL ? 0 : (blockIdx.y & 1), tile = FULL ? blockIdx.y : (blockIdx.y >> 1);       // B <= 8: a single batch tile (blockIdx.x == 0)
     const int KS = K / 32;
     const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);       // k1 - k0 <= G (launcher)
     const int m = lane & 15, g = lane >> 4;
-    const bool epi = wv == 15 && m < B && g < 2;
-    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, (m & 7) + 8 * half);
-    bf16_t* hp = h + (size_t)min(m, B - 1) * N + tile * 16 + 8 * half + 4 * (g & 1);
+    const bool epi = wv == 15 && m < B && (FULL || g < 2);
+    const WT* wp = Wd + ((size_t)tile * KS) * 64 + lane_slot<WT>(g, FULL ? m : (m & 7) + 8 * half);
+    const int col0 = tile * 16 + (FULL ? 4 * g : 8 * half + 4 * (g & 1));
+    bf16_t* hp = h + (size_t)min(m, B - 1) * N + col0;
     TRACE(0);
     const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + tile * 16 + 8 * half + 4 * (g & 1));
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + col0);
     // this wave's k-steps live in image bytes [512 k0, 512 k1): 1 KiB pieces p0 .. (a piece shared with the neighbour wave is
     // copied by both: same bytes)
     const int p0 = k0 >> 1, plast = (KS - 1) >> 1;
@@ -486,56 +490,54 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
 // fragment image (launch_pack_frag_fp8) and wscale its per-row fp32 scales.
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
-                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps) {
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int full_tiles) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
-    static uint32_t attr[2] = {0, 0};
+    static uint32_t attr[4] = {0, 0, 0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
-    const dim3 grid((B + 15) / 16, (Hq + 2 * Hkv) * 16);
-    if (wscale) {
-        hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, u32x2>, lds_max, &attr[1]);
+    const dim3 grid((B + 15) / 16, (Hq + 2 * Hkv) * (full_tiles ? 8 : 16));
+    auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+        hipError_t e = ensure_lds(kern, lds_max, done);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dec_qkv_kernel<NC_MAX, u32x2>), grid, dim3(1024), lds, s, h, ln_w, (const u32x2*)Wd, wscale, bias, inv_freq, ctx_len,
-                           block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
-    } else {
-        hipError_t e = ensure_lds(dec_qkv_kernel<NC_MAX, bf16x8>, lds_max, &attr[0]);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((dec_qkv_kernel<NC_MAX, bf16x8>), grid, dim3(1024), lds, s, h, ln_w, (const bf16x8*)Wd, wscale, bias, inv_freq, ctx_len,
-                           block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
-    }
-    return hipGetLastError();
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, h, ln_w, wd, wscale, bias, inv_freq, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, XR);
+        return hipGetLastError();
+    };
+    if (wscale) return full_tiles ? go(dec_qkv_kernel<NC_MAX, u32x2, true>, (const u32x2*)Wd, &attr[3]) : go(dec_qkv_kernel<NC_MAX, u32x2, false>, (const u32x2*)Wd, &attr[1]);
+    return full_tiles ? go(dec_qkv_kernel<NC_MAX, bf16x8, true>, (const bf16x8*)Wd, &attr[2]) : go(dec_qkv_kernel<NC_MAX, bf16x8, false>, (const bf16x8*)Wd, &attr[0]);
 }
 
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K) {
+// full_tiles: one whole 16-row tile per workgroup (N / 16 workgroups) instead of an 8-row half tile — for a stream CU-masked to half the chip.
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int full_tiles) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
-    const dim3 grid((B + 15) / 16, N / 8);
-#define PROJ_CASE(G)                                                                                                                   \
-    do {                                                                                                                               \
-        if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);  \
-        else hipLaunchKernelGGL((dec_proj_kernel<G, bf16x8>), grid, dim3(1024), 0, s, X, (const bf16x8*)Wd, wscale, h, B, N, K, XR);       \
+    const dim3 grid((B + 15) / 16, full_tiles ? N / 16 : N / 8);
+#define PROJ_LAUNCH(G, F)                                                                                                                        \
+    do {                                                                                                                                         \
+        if (wscale) hipLaunchKernelGGL((dec_proj_kernel<G, u32x2, F>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);      \
+        else hipLaunchKernelGGL((dec_proj_kernel<G, bf16x8, F>), grid, dim3(1024), 0, s, X, (const bf16x8*)Wd, wscale, h, B, N, K, XR);           \
     } while (0)
+#define PROJ_CASE(G) do { if (full_tiles) PROJ_LAUNCH(G, true); else PROJ_LAUNCH(G, false); } while (0)
     static const bool no_lds = getenv("DOTS_OCR_PROJ_REG") != nullptr;            // A/B switch: the register-round kernel for long K too
     const size_t lds_x = (size_t)16 * K + 16 * 64 * sizeof(f32x4);
     if (!no_lds && B <= 8 && need > 4 && need <= PROJ_LDS_G && lds_x <= 160 * 1024) {
-        static uint32_t attr_l[2] = {0, 0};
-        hipError_t e;
-        if (wscale) {
-            if ((e = ensure_lds(dec_proj_lds_kernel<u32x2>, lds_x, &attr_l[1])) != hipSuccess) return e;
-            hipLaunchKernelGGL((dec_proj_lds_kernel<u32x2>), grid, dim3(1024), lds_x, s, X, (const u32x2*)Wd, wscale, h, B, N, K);
-        } else {
-            if ((e = ensure_lds(dec_proj_lds_kernel<bf16x8>, lds_x, &attr_l[0])) != hipSuccess) return e;
-            hipLaunchKernelGGL((dec_proj_lds_kernel<bf16x8>), grid, dim3(1024), lds_x, s, X, (const bf16x8*)Wd, wscale, h, B, N, K);
-        }
-        return hipGetLastError();
+        static uint32_t attr_l[4] = {0, 0, 0, 0};
+        auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+            hipError_t e = ensure_lds(kern, lds_x, done);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds_x, s, X, wd, wscale, h, B, N, K);
+            return hipGetLastError();
+        };
+        if (wscale) return full_tiles ? go(dec_proj_lds_kernel<u32x2, true>, (const u32x2*)Wd, &attr_l[3]) : go(dec_proj_lds_kernel<u32x2, false>, (const u32x2*)Wd, &attr_l[1]);
+        return full_tiles ? go(dec_proj_lds_kernel<bf16x8, true>, (const bf16x8*)Wd, &attr_l[2]) : go(dec_proj_lds_kernel<bf16x8, false>, (const bf16x8*)Wd, &attr_l[0]);
     }
     if (need <= 1) PROJ_CASE(1);
     else if (need <= 2) PROJ_CASE(2);
     else if (need <= 3) PROJ_CASE(3);
     else if (need <= 4) PROJ_CASE(4);
-    else if (wscale) hipLaunchKernelGGL((dec_proj_kernel<PROJ_G_FP8, u32x2>), grid, dim3(1024), 0, s, X, (const u32x2*)Wd, wscale, h, B, N, K, XR);
+    else if (wscale) { if (full_tiles) PROJ_LAUNCH(PROJ_G_FP8, true); else PROJ_LAUNCH(PROJ_G_FP8, false); }
     else PROJ_CASE(6);
 #undef PROJ_CASE
+#undef PROJ_LAUNCH
     return hipGetLastError();
 }
 

@@ -178,7 +178,8 @@ struct DotsEngine {
     int out_cap = 0;                       // row stride of out_ids for the current generation
     bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
-    // decode layer launch plan: 0 = one launch per phase, 1 = [qkv -> attention] and [o_proj -> gate|up] fused (decode_flow.hip; B <= 8)
+    // decode layer launch plan: 0 = one launch per phase, 1 = [qkv -> attention] and [o_proj -> gate|up] fused (decode_flow.hip; B <= 8),
+    // 2 = one launch per phase with the half-chip plan (whole-tile projections) on every step
     int flow_mode = 0;
     bf16_t* d_qkvn = nullptr;              // [max_batch][(Hq + 2 Hkv) * 128]: q | k | v of the token of this step
     uint32_t *flow_sync = nullptr, *flow_err = nullptr;
@@ -198,7 +199,7 @@ struct DotsEngine {
     const int32_t* sel_now = nullptr;      // selection mask of the next select_tokens() call
     // captured decode steps, keyed by everything the capture bakes in: rows, KV splits, static batch (out_cap = row stride of
     // the output buffer) or slot mode (out_cap = 0), number of EOS ids; sampling changes drop the cache (dots_set_sampling)
-    struct StepGraph { int rows, splits, out_cap, n_eos; hipGraph_t graph; hipGraphExec_t exec; };
+    struct StepGraph { int rows, splits, out_cap, n_eos, part; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<StepGraph> step_graphs;
     std::vector<int> h_prompt_lens;
     int steps_done = 0;
@@ -562,7 +563,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->flow_sync, e->flow_sync_bytes / 4));
     CK(e->alloc(&e->flow_err, (size_t)16));
     CK(hipMemsetAsync(e->flow_err, 0, 64, e->stream));
-    if (const char* fm = getenv("DOTS_OCR_FLOW")) e->flow_mode = atoi(fm) ? 1 : 0;
+    if (const char* fm = getenv("DOTS_OCR_FLOW")) e->flow_mode = std::max(0, std::min(2, atoi(fm)));
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
     // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
     e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
@@ -759,9 +760,18 @@ int ensure_overlap_streams(DotsEngine* e) {
     if (e->s_vit) return DOTS_OK;
     if (const char* v = getenv("DOTS_OCR_OVERLAP_DEC_CUS")) e->dec_cus = std::max(32, std::min(224, atoi(v) / 8 * 8));
     uint32_t wd[8] = {0}, wv[8] = {0};
-    for (int b = 0; b < 256; ++b) (b < e->dec_cus ? wd : wv)[b / 32] |= 1u << (b % 32);
-    CK(hipExtStreamCreateWithCUMask(&e->s_dec, 8, wd));
-    CK(hipExtStreamCreateWithCUMask(&e->s_vit, 8, wv));
+    // DOTS_OCR_OVERLAP_BY_XCD=1 (experiment): whole XCDs instead of an equal share of every XCD — the decode loop gets XCDs 0 .. dec_cus / 32 - 1
+    static const bool by_xcd = getenv("DOTS_OCR_OVERLAP_BY_XCD") != nullptr;
+    for (int b = 0; b < 256; ++b) ((by_xcd ? (b % 8) < e->dec_cus / 32 : b < e->dec_cus) ? wd : wv)[b / 32] |= 1u << (b % 32);
+    // A device that refuses CU masks (another compute-partition mode, fewer CUs) still gets correct results: plain streams then
+    // time-slice the chip, i.e. the prefetch degenerates to the sequential schedule.
+    if (hipExtStreamCreateWithCUMask(&e->s_dec, 8, wd) != hipSuccess || hipExtStreamCreateWithCUMask(&e->s_vit, 8, wv) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e->s_dec) { hipStreamDestroy(e->s_dec); e->s_dec = nullptr; }
+        fprintf(stderr, "[dots_ocr_hip] CU-masked streams are not available on this device: vision prefetch runs without CU partitioning\n");
+        CK(hipStreamCreateWithFlags(&e->s_dec, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&e->s_vit, hipStreamNonBlocking));
+    }
     CK(hipEventCreateWithFlags(&e->ev_vis_ready, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&e->ev_xs, hipEventDisableTiming));
     return DOTS_OK;
@@ -967,14 +977,16 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
 }
 
 // every launch of one decode step; identical in eager mode and under graph capture
-int decode_step_launches(DotsEngine* e, int n_splits) {
+// part: the launch plan for a stream that is CU-masked to half the chip (whole 16-row tiles: half as many workgroups per projection)
+int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->stream;
     const int H = c.hidden_size, Hq = c.num_heads, Hkv = c.num_kv_heads, Nq = Hq * 128, I = c.intermediate_size;
     const int B = e->B;
     const float scale = 1.0f / sqrtf(128.0f);
     CK(launch_dec_embed(s, e->cur_tokens, e->embed, e->d_h, B, H));
-    const bool flow = e->flow_mode > 0 && flow_supported(B, H, Hq, Hkv, I);
+    const bool flow = e->flow_mode == 1 && flow_supported(B, H, Hq, Hkv, I);
+    if (e->flow_mode == 2 && B <= 8) part = 1;                                     // dots_set_decode_flow(2): the half-chip plan on every step (tests, A/B runs)
     if (flow) CK(hipMemsetAsync(e->flow_sync, 0, e->flow_sync_bytes, s));         // a memset node at the head of every replay
     static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
     for (int i = 0; i < c.num_layers; ++i) {
@@ -993,12 +1005,12 @@ int decode_step_launches(DotsEngine* e, int n_splits) {
             continue;
         }
         CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
-                          Hkv, c.rms_norm_eps));
+                          Hkv, c.rms_norm_eps, part));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
-        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq));
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part));
         CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps));
-        CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I));
+        CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part));
     }
     CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = B;
@@ -1022,13 +1034,13 @@ int flow_check(DotsEngine* e) {
 }
 
 // The captured decode step for (rows = e->B, splits, out_cap, e->n_eos): looked up in the cache or captured now.
-int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_t* exec) {
+int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_t* exec, int part = 0) {
     for (auto& g : e->step_graphs)
-        if (g.rows == rows && g.splits == n_splits && g.out_cap == out_cap && g.n_eos == e->n_eos) { *exec = g.exec; return DOTS_OK; }
+        if (g.rows == rows && g.splits == n_splits && g.out_cap == out_cap && g.n_eos == e->n_eos && g.part == part) { *exec = g.exec; return DOTS_OK; }
     if (e->step_graphs.size() >= 32) drop_step_graphs(e);
-    DotsEngine::StepGraph g{rows, n_splits, out_cap, e->n_eos, nullptr, nullptr};
+    DotsEngine::StepGraph g{rows, n_splits, out_cap, e->n_eos, part, nullptr, nullptr};
     CK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    int r = decode_step_launches(e, n_splits);
+    int r = decode_step_launches(e, n_splits, part);
     hipError_t ce = hipStreamEndCapture(e->stream, &g.graph);
     if (r != DOTS_OK || ce != hipSuccess) {
         if (ce == hipSuccess && g.graph) hipGraphDestroy(g.graph);
@@ -1300,9 +1312,13 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     std::vector<int32_t> fin(DOTS_MAX_BATCH);
     int steps = 0;
     hipStream_t cur = s;                           // where the decode graph is replayed: see pick_decode_stream
+    hipGraphExec_t exec_part = nullptr;            // the step captured with the half-chip launch plan, for the masked stream
     for (int step = 1; step < max_new_tokens; ++step) {
-        if (exec && (step & 15) == 1) RET(pick_decode_stream(e, &cur));
-        if (exec) CK(hipGraphLaunch(exec, cur));
+        if (exec && (step & 15) == 1) {
+            RET(pick_decode_stream(e, &cur));
+            if (cur != s && !exec_part && B <= 8 && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
+        }
+        if (exec) CK(hipGraphLaunch(cur != s && exec_part ? exec_part : exec, cur));
         else RET(decode_step_launches(e, n_splits));
         ++steps;
         if (n_eos && (step % 16 == 0)) {       // early exit once every sequence hit EOS
@@ -1578,7 +1594,7 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
 
 int dots_set_decode_flow(DotsEngine* e, int mode) {
     if (!e) return DOTS_E_INVALID;
-    if (mode < 0 || mode > 1) return e->fail(DOTS_E_INVALID, "decode flow mode must be 0 or 1");
+    if (mode < 0 || mode > 2) return e->fail(DOTS_E_INVALID, "decode flow mode must be 0, 1 or 2");
     if (mode != e->flow_mode) {
         e->flow_mode = mode;
         drop_step_graphs(e);                               // the captured decode steps bake the launch plan in

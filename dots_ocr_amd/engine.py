@@ -312,7 +312,8 @@ class Engine:
         self._ck(self.lib.dots_set_sampling(self.h, float(temperature), float(top_p), int(seed) & (2 ** 64 - 1)), "dots_set_sampling")
 
     def set_decode_flow(self, mode: int):
-        """0 = one launch per decode phase, 1 = [qkv -> attention] and [o_proj -> gate|up] fused into one launch each (B <= 8; bit-identical)."""
+        """0 = one launch per decode phase, 1 = [qkv -> attention] and [o_proj -> gate|up] fused into one launch each, 2 = the half-chip
+        launch plan (whole-tile projections) on every step; B <= 8, all bit-identical."""
         self._ck(self.lib.dots_set_decode_flow(self.h, int(mode)), "dots_set_decode_flow")
 
     def decode_step(self):

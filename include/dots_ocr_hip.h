@@ -158,9 +158,12 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, 
  * parameters the reference passes to its vLLM backend (parser.py:27-28, model/inference.py:38-43).  Reproducible
  * from `seed` (counter-based: seed, batch slot, position). */
 int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed);
-/* Launch plan of the decode step for batches of <= 8 sequences (results are bit-identical in both modes): 1 = [qkv -> attention] and
+/* Launch plan of the decode step for batches of <= 8 sequences (results are bit-identical in every mode): 1 = [qkv -> attention] and
  * [o_proj -> gate|up] as ONE launch each, the second phase chained to the first by an in-launch hand-off (csrc/decode_flow.hip);
- * 0 = one launch per phase (also what larger batches use).  Environment DOTS_OCR_FLOW sets the default.  A hand-off that times out
+ * 0 = one launch per phase (also what larger batches use); 2 = one launch per phase with the HALF-CHIP plan — qkv / o_proj / down_proj
+ * as whole 16-row tiles, half as many workgroups — which dots_generate otherwise uses only while it replays the step on its 128-CU
+ * partition beside a prefetched vision tower (there: 1.88 -> 1.67 ms per step; on the whole chip it is slower).  Environment
+ * DOTS_OCR_FLOW sets the default.  A hand-off that times out
  * fails the call that next synchronises with DOTS_E_HIP — never a hang. */
 int dots_set_decode_flow(DotsEngine* e, int mode);
 

@@ -1,4 +1,4 @@
-"""The fused decode launches (csrc/decode_flow.hip: [qkv -> attention] and [o_proj -> gate|up] as ONE launch each, the second role
+"""Alternative launch plans of the decode step — mode 1: the fused decode launches (csrc/decode_flow.hip: [qkv -> attention] and [o_proj -> gate|up] as ONE launch each, the second role
 chained to the first by an in-launch hand-off) must produce EXACTLY the bits of the launch-per-phase kernels they replace
 (decode_fused.hip / decode.hip, parity-tested against the oracle in test_decode_kernels_gpu.py / test_fullsize_parity_gpu.py): same
 arithmetic, same reduction order, only the schedule and the transport of the activations differ.  Compared through the C ABI
@@ -8,6 +8,8 @@ Edge cases the hand-offs add: the token of the step is patched into the prefetch
 (first / last key of a page, a page that starts with this token), sequences of different lengths in one batch (idle splits),
 contexts beyond 4 x 64 pages (a wave walks several pages), fp8 weights, repeated graph replays (the sync words are re-armed by
 the memset node of every replay), and a batch of 9 that must fall back to the launch-per-phase kernels.
+Mode 2: the half-chip plan (whole 16-row tiles in dec_qkv / dec_proj: what dots_generate replays on its 128-CU partition beside a
+prefetched vision tower) — the same bits as well.
 """
 import numpy as np
 import pytest
@@ -62,7 +64,7 @@ def test_flow_modes_equal_launch_per_phase_bitwise(tiny, lens):
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, lens, seed=len(lens))
     ref = _decode(eng, 0, ids, ln, 6)
-    for mode in (1,):
+    for mode in (1, 2):
         _assert_same(ref, _decode(eng, mode, ids, ln, 6), f"flow mode {mode}, prompt lengths {lens}")
 
 
@@ -71,10 +73,10 @@ def test_flow_under_graph_replay_and_generate(tiny):
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, [40, 90, 64, 33], seed=9)
     out = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         eng.set_decode_flow(mode)
         out[mode] = eng.generate(ids, ln, max_new_tokens=80)
-    for m in (1,):
+    for m in (1, 2):
         for a, b in zip(out[0], out[m]):
             assert np.array_equal(np.asarray(a), np.asarray(b))
 
@@ -95,7 +97,7 @@ def test_flow_walks_several_pages_per_wave_beyond_16k_context():
     eng.load_state_dict(sd)
     ids, ln = _prompts(cfg, [16500, 16383], seed=4)
     ref = _decode(eng, 0, ids, ln, 3)
-    for mode in (1,):
+    for mode in (1, 2):
         _assert_same(ref, _decode(eng, mode, ids, ln, 3), f"16.5k-token contexts, mode {mode}")
     eng.close()
 
@@ -110,7 +112,7 @@ def test_flow_fp8_equals_launch_per_phase_bitwise():
     ref = _decode(eng, 0, ids, ln, 5)
     ref2 = _decode(eng, 0, ids, ln, 5)
     _assert_same(ref, ref2, "fp8, launch-per-phase run twice")
-    for mode in (1,):
+    for mode in (1, 2):
         got = _decode(eng, mode, ids, ln, 5)
         for s_, (a, b) in enumerate(zip(ref[0], got[0])):
             bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
@@ -134,6 +136,6 @@ def test_flow_at_the_real_dimensions_bitwise():
     eng.load_state_dict(sd)
     ids, ln = _prompts(cfg, lens, seed=3)
     ref = _decode(eng, 0, ids, ln, 5)
-    for mode in (1,):
+    for mode in (1, 2):
         _assert_same(ref, _decode(eng, mode, ids, ln, 5), f"real dimensions, flow mode {mode}")
     eng.close()

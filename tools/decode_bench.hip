@@ -105,6 +105,12 @@ int main(int argc, char** argv) {
     const int L = 28, H = 1536, Hq = 12, Hkv = 2, I = 8960, V = 151936, Nq = Hq * 128, NQKV = (Hq + 2 * Hkv) * 128;
     const float eps = 1e-6f;
     CK(hipSetDevice(0));
+    if (const char* cr = getenv("DOTS_BENCH_CUS")) {          // run on the first N CU-mask bits only (N / 8 CUs of every XCD): the decode partition of the pipelined step
+        uint32_t words[8] = {0};
+        for (int b = 0; b < atoi(cr) && b < 256; ++b) words[b / 32] |= 1u << (b % 32);
+        CK(hipExtStreamCreateWithCUMask(&S, 8, words));
+        printf("stream masked to %d CUs\n", atoi(cr));
+    } else
     CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
 #ifdef DOTS_TRACE
     CK(hipMalloc(&g_trace, TRACE_WORDS * 8));
@@ -152,12 +158,13 @@ int main(int argc, char** argv) {
     st.cur_tokens = cur; st.ctx_len = ctx_len; st.out_ids = out_ids; st.out_lens = out_lens; st.finished = fin; st.eos_ids = nullptr; st.sel = nullptr;
     st.max_len = nullptr; st.n_eos = 0; st.out_stride = 64; st.cap = 1; st.advance_ctx = 0;       // cap 1: rows finish at once, ctx stays put
 
-    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps)); };
+    const int full = getenv("DOTS_BENCH_FULL") ? 1 : 0;      // whole-tile projections (the half-chip launch plan)
+    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, full)); };
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
-    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq)); };
+    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, full)); };
     auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps)); };
-    auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I)); };
+    auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I, full)); };
     auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps)); };
     // skip: bit mask of kernel kinds left out (marginal cost of a kind inside the real, HBM-cold step = full - skipped)
     auto step_skip = [&](int skip) {
