@@ -109,7 +109,7 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
             raw["vit_1_block_s"].append(t1)
             raw["vit_3_blocks_s"].append(t3)
         emb = om.build_embeds(sd, cfg, t_ids, vis)
-        n_dec = 4
+        n_dec = 16
         res = {}
         for layers in (1, 3):
             c = cfg_with(1, layers)
