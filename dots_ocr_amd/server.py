@@ -222,13 +222,15 @@ def _parse_messages(messages, processor=None, allow_remote: bool = False, allow_
         for c in content or []:
             if c.get("type") == "image_url":
                 url = c["image_url"]["url"] if isinstance(c["image_url"], dict) else c["image_url"]
+                if image is not None:                  # one page per request, like the reference client (model/inference.py:23-43)
+                    raise ValueError("exactly one image per request is supported")
                 image = _load_request_image(url, allow_remote, allow_local)
                 items.append({"type": "image", "image": "request"})
             elif c.get("type") == "text":
                 items.append({"type": "text", "text": c["text"]})
         conv.append({"role": role, "content": items})
-    if any(IMG_PAD in it.get("text", "") for m in conv for it in m["content"]):       # placeholders already in the text
-        for m in conv:
+    for m in conv:                                    # placeholders already written into THIS message's text: drop its image item
+        if any(IMG_PAD in it.get("text", "") for it in m["content"]):
             m["content"] = [it for it in m["content"] if it.get("type") != "image"]
     if processor is not None:
         return image, processor.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)

@@ -174,3 +174,20 @@ def test_server_refuses_remote_and_local_image_locations_by_default(tmp_path):
     own = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": PILimage_to_base64(Image.new("RGB", (28, 28)))}},
                                          {"type": "text", "text": "<|img|><|imgpad|><|endofimg|>read"}]}]
     assert _parse_messages(own)[1].count("<|imgpad|>") == 1
+
+
+def test_server_rejects_a_second_image_and_keeps_other_messages_images():
+    """ADVICE r2: two image_url parts used to render two placeholder blocks for ONE kept image (an opaque token-count mismatch later);
+    and a placeholder written into one message's text must not strip the image item of another message."""
+    from PIL import Image
+    from dots_ocr_amd.image_utils import PILimage_to_base64
+    from dots_ocr_amd.server import _parse_messages
+    u = PILimage_to_base64(Image.new("RGB", (28, 28), "blue"))
+    two = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": u}}, {"type": "image_url", "image_url": {"url": u}},
+                                        {"type": "text", "text": "read"}]}]
+    with pytest.raises(ValueError, match="exactly one image"):
+        _parse_messages(two)
+    mixed = [{"role": "system", "content": [{"type": "text", "text": "about <|imgpad|> tokens"}]},
+             {"role": "user", "content": [{"type": "image_url", "image_url": {"url": u}}, {"type": "text", "text": "read"}]}]
+    img, text = _parse_messages(mixed)
+    assert img is not None and text.count("<|img|><|imgpad|><|endofimg|>") == 1
