@@ -819,6 +819,7 @@ int launch_prefetched_tower(DotsEngine* e) {
     int r = vit_forward(e, e->pref_pix, e->pref_patches, e->pref_grid.data(), (int)(e->pref_grid.size() / 3), nullptr, e->vis_pref, &e->vis_pref_rows);
     e->vs = e->stream;
     CK(hipEventRecord(e->ev_vis_ready, e->s_vit));
+    if (r != DOTS_OK) e->pref_pending = false;           // nothing to take
     return r;
 }
 
@@ -1308,16 +1309,17 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);       // engine constant: results do not depend on the batch
     const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
     hipGraphExec_t exec = nullptr;
-    if (use_graph && max_new_tokens > 1) RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
+    hipGraphExec_t exec_part = nullptr;            // the step captured with the half-chip launch plan, for the masked stream
+    if (use_graph && max_new_tokens > 1) {
+        if (e->step_graphs.size() >= 30) drop_step_graphs(e);          // so that neither lookup below can evict the other's graph
+        if (e->s_vit && B <= 8 && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
+        RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
+    }
     std::vector<int32_t> fin(DOTS_MAX_BATCH);
     int steps = 0;
     hipStream_t cur = s;                           // where the decode graph is replayed: see pick_decode_stream
-    hipGraphExec_t exec_part = nullptr;            // the step captured with the half-chip launch plan, for the masked stream
     for (int step = 1; step < max_new_tokens; ++step) {
-        if (exec && (step & 15) == 1) {
-            RET(pick_decode_stream(e, &cur));
-            if (cur != s && !exec_part && B <= 8 && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
-        }
+        if (exec && (step & 15) == 1) RET(pick_decode_stream(e, &cur));
         if (exec) CK(hipGraphLaunch(cur != s && exec_part ? exec_part : exec, cur));
         else RET(decode_step_launches(e, n_splits));
         ++steps;
