@@ -398,6 +398,12 @@ def main():
                     for o in (r, rv):
                         o["cus"] = cus_vit
                         o["frac_of_partition_peak"] = o["frac"] * 256.0 / cus_vit
+                        o["note"] = (f"timed region = software-pipelined batches: this kernel runs on a {cus_vit}-CU partition while the other {256 - cus_vit} CUs replay the "
+                                     "decode loop of the previous batch, so `frac` (against the WHOLE chip's peak) is by construction about half of what the same "
+                                     "kernel reaches alone on the chip — that figure, measured in the sequential batch this run starts with, is in roofline_sequential / "
+                                     "roofline_vit_sequential; whole-step utilisation is in roofline_step")
+                    rd["note"] = ("timed region = software-pipelined batches: most decode steps run on the decode partition beside the next batch's vision tower "
+                                  "(half-chip launch plan); the step alone on the whole chip is in roofline_decode_sequential")
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
