@@ -1433,16 +1433,22 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);
     e->B = rows;
     static const bool use_graph = getenv("DOTS_OCR_NO_GRAPH") == nullptr;
+    // beside a prefetched vision tower (the next admission's: dots_vit_prefetch) the chunk is replayed on the decode partition, with the
+    // half-chip launch plan when the rows allow it — exactly as dots_generate does
+    hipStream_t cur = s;
+    if (use_graph) { int r0 = pick_decode_stream(e, &cur); if (r0 != DOTS_OK) { e->B = 0; return r0; } }
+    const int part = (cur != s && rows <= 8 && e->flow_mode == 0) ? 1 : 0;
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
-        int r = step_graph(e, rows, n_splits, 0, &exec);
+        int r = step_graph(e, rows, n_splits, 0, &exec, part);
         if (r != DOTS_OK) { e->B = 0; return r; }
     }
     int r = DOTS_OK;
     for (int i = 0; i < n_steps && r == DOTS_OK; ++i) {
-        if (exec) { if (hipGraphLaunch(exec, s) != hipSuccess) r = e->fail(DOTS_E_HIP, "hipGraphLaunch failed"); }
+        if (exec) { if (hipGraphLaunch(exec, cur) != hipSuccess) r = e->fail(DOTS_E_HIP, "hipGraphLaunch failed"); }
         else r = decode_step_launches(e, n_splits);
     }
+    if (r == DOTS_OK) r = chain_streams(e, cur, s);
     e->B = 0;
     e->stats.decode_steps += n_steps;
     return r;

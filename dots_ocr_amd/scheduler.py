@@ -36,10 +36,17 @@ class Request:
 class ContinuousBatcher:
     """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
 
-    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: int = 2):
+    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: int = 2, prefetch: int = 0):
         self.engine = engine
         self.chunk = max(1, int(chunk))
         self.headroom_pages = max(0, int(headroom_pages))       # free KV pages kept per running sequence when admitting (see plan_admission)
+        # look-ahead: the vision tower of the next `prefetch` queued requests runs on the engine's CU-masked side stream while the
+        # occupied slots keep decoding on the other CU partition (Engine.vit_prefetch); that group is then admitted as a whole — prefill
+        # only, no tower in the decode loop's way — as soon as it has the slots and pages.  1 suits requests that finish at different
+        # times (a slot is refilled as soon as it frees), n_slots suits closed sets of equal length.  0 = off.
+        self.prefetch = max(0, int(prefetch)) if hasattr(engine, "vit_prefetch") else 0
+        self._ahead: List[Tuple[int, Request]] = []             # requests whose tower has been prefetched, in packed order
+        self._ahead_keep = None                                  # their (device) pixels stay alive until the rows are taken
         self.n_slots = int(engine.max_batch)
         self.max_patches = int(engine.max_patches)
         self.max_prefill_tokens = int(engine.max_prefill_tokens)
@@ -80,7 +87,7 @@ class ContinuousBatcher:
 
     @property
     def idle(self) -> bool:
-        return not self.pending and not self.running
+        return not self.pending and not self.running and not self._ahead
 
     def free_slots(self) -> List[int]:
         return [s for s in range(self.n_slots) if s not in self.running]
@@ -116,21 +123,20 @@ class ContinuousBatcher:
             tokens += t
         return group
 
-    def _admit(self, group):
-        with_img = [(s, rid, r) for s, rid, r in group if r.n_patches() > 0]
-        if with_img:
-            grid = np.concatenate([np.asarray(r.grid_thw, dtype=np.int64).reshape(-1, 3) for _, _, r in with_img])
-            pvs = [r.pixel_values for _, _, r in with_img]
-            if all(hasattr(p, "is_cuda") and p.is_cuda for p in pvs):
-                import torch
-                pv = pvs[0] if len(pvs) == 1 else torch.cat(pvs, dim=0)
-                pv = pv.contiguous().float()
-                torch.cuda.synchronize(pv.device)
-                self.engine.vit_forward(pv.data_ptr(), grid, on_device=True)
-                self.engine.synchronize()            # `pv` may be a temporary
-            else:
-                host = [p.detach().cpu().numpy() if hasattr(p, "detach") else np.asarray(p) for p in pvs]
-                self.engine.vit_forward(np.concatenate(host).astype(np.float32, copy=False), grid)
+    def _pixels(self, with_img):
+        """(pixel values, grid, on_device, keep-alive) of the requests' images, packed in order"""
+        grid = np.concatenate([np.asarray(r.grid_thw, dtype=np.int64).reshape(-1, 3) for _, r in with_img])
+        pvs = [r.pixel_values for _, r in with_img]
+        if all(hasattr(p, "is_cuda") and p.is_cuda for p in pvs):
+            import torch
+            pv = pvs[0] if len(pvs) == 1 else torch.cat(pvs, dim=0)
+            pv = pv.contiguous().float()
+            torch.cuda.synchronize(pv.device)
+            return pv.data_ptr(), grid, True, pv
+        host = [p.detach().cpu().numpy() if hasattr(p, "detach") else np.asarray(p) for p in pvs]
+        return np.concatenate(host).astype(np.float32, copy=False), grid, False, None
+
+    def _prefill(self, group):
         # image rows are consumed in packed order, so sequences with images keep their relative order: pack the group as is
         slots = [s for s, _, _ in group]
         lens = [int(r.input_ids.shape[0]) for _, _, r in group]
@@ -139,6 +145,52 @@ class ContinuousBatcher:
         for s, rid, r in group:
             self.running[s] = (rid, r)
         self.admissions += 1
+
+    def _admit(self, group):
+        with_img = [(rid, r) for _, rid, r in group if r.n_patches() > 0]
+        if with_img:
+            pv, grid, on_dev, keep = self._pixels(with_img)
+            self.engine.vit_forward(pv, grid, on_device=on_dev)
+            if on_dev:
+                self.engine.synchronize()            # `keep` may be a temporary
+        self._prefill(group)
+
+    # ------------------------------------------------------------------ look-ahead (prefetched towers)
+    def _admit_ahead(self) -> bool:
+        """The group whose tower was prefetched goes in as a whole as soon as it has the slots and the pages."""
+        free = self.free_slots()
+        if len(free) < len(self._ahead):
+            return False
+        if hasattr(self.engine, "kv_pool_info"):
+            need = sum(self._admit_pages(int(r.input_ids.shape[0]), r.max_new_tokens) for _, r in self._ahead)
+            reserve = self.headroom_pages * (len(self.running) + len(self._ahead)) if self.running else 0
+            if need + reserve > self.engine.kv_pool_info()[1]:
+                return False
+        self.engine.vit_take()
+        self._prefill([(free[i], rid, r) for i, (rid, r) in enumerate(self._ahead)])
+        self._ahead, self._ahead_keep = [], None
+        return True
+
+    def _look_ahead(self):
+        """Start the tower of the next queued requests (FIFO prefix, image requests only) on the side stream."""
+        if not self.prefetch or self._ahead or not self.pending:
+            return
+        total_pages = self.engine.kv_pool_info()[0] if hasattr(self.engine, "kv_pool_info") else 1 << 30
+        group, patches, tokens, pages = [], 0, 0, 0
+        while self.pending and len(group) < min(self.prefetch, self.n_slots):
+            rid, req = self.pending[0]
+            p, t = req.n_patches(), int(req.input_ids.shape[0])
+            pg = self._admit_pages(t, req.max_new_tokens)
+            if p == 0 or patches + p > self.max_patches or tokens + t > self.max_prefill_tokens or pages + pg > total_pages:
+                break                                # a text-only request goes through the ordinary admission, in its turn
+            self.pending.popleft()
+            group.append((rid, req))
+            patches, tokens, pages = patches + p, tokens + t, pages + pg
+        if not group:
+            return
+        pv, grid, on_dev, keep = self._pixels(group)
+        self.engine.vit_prefetch(pv, grid, on_device=on_dev)
+        self._ahead, self._ahead_keep = group, keep
 
     # ------------------------------------------------------------------ main loop
     def _collect(self) -> List[Tuple[int, Request, np.ndarray]]:
@@ -153,13 +205,21 @@ class ContinuousBatcher:
 
     def step(self) -> List[Tuple[int, Request, np.ndarray]]:
         """Admit what fits, run one decode chunk, return the requests that finished: (id, request, new token ids)."""
-        group = self.plan_admission()
-        if group:
-            self._admit(group)
+        if self._ahead:                              # a prefetched group waits for its slots: nothing may overtake it
+            admitted = self._admit_ahead()
+        else:
+            group = self.plan_admission()
+            admitted = bool(group)
+            if group:
+                self._admit(group)
+        self._look_ahead()
+        if admitted:
             done = self._collect()                   # a 1-token cap or an immediate EOS finishes at prefill
             if done:
                 return done
         if not self.running:
+            if self._ahead:                          # nothing runs, so every slot and page is free: the group fits by construction
+                raise RuntimeError("a prefetched group could not be admitted into an empty engine")
             if self.pending:                         # nothing runs, nothing could be admitted: it never will be
                 rid, req = self.pending.popleft()
                 raise RuntimeError(f"request {rid} ({req.input_ids.shape[0]} prompt tokens, {req.n_patches()} patches) cannot be admitted "

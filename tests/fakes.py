@@ -26,6 +26,16 @@ class FakeSlotEngine:
     def vit_forward(self, pv, grid, on_device=False):
         self.log.append(("vit", int(np.asarray(grid)[:, 1:].prod(axis=1).sum()), len(pv)))
 
+    def vit_prefetch(self, pv, grid, on_device=False, after_prefill=False):
+        assert not getattr(self, "_pref", None), "a prefetched batch is waiting"
+        self._pref = int(np.asarray(grid)[:, 1:].prod(axis=1).sum())
+        self.log.append(("prefetch", self._pref, len(pv)))
+
+    def vit_take(self):
+        assert getattr(self, "_pref", None), "nothing prefetched"
+        self.log.append(("take", self._pref))
+        self._pref = None
+
     def _advance(self, st):
         if st["done"]:
             return

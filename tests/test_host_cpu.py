@@ -578,3 +578,45 @@ def test_pdf_rasteriser_scanned_pages_like_the_reference(tmp_path):
         objs[5] = (b"<< /Length %d >>" % len(bad), bad)
         with pytest.raises(du.PdfContentNotSupported):
             du.fitz_doc_to_image(du.PdfDocument(_pdf(objs))[0])
+
+
+def test_continuous_batcher_look_ahead_prefetches_the_next_towers_with_a_fake_engine():
+    """Scheduler logic only: with prefetch = k the towers of the next k queued image requests are started on the side stream while the slots
+    decode, that group is admitted as a whole (take + prefill, no tower call) as soon as it has k free slots, nothing overtakes it, text-only
+    requests go through the ordinary admission, and every request still gets exactly its own tokens."""
+    import numpy as np
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    from fakes import FakeSlotEngine
+
+    def req(first, n_tok, cap, patches=0):
+        ids = np.full(n_tok, first, np.int32)
+        if patches:
+            return Request(ids, np.zeros((patches, 4), np.float32), np.array([[1, patches // 2, 2]]), cap)
+        return Request(ids, None, None, cap)
+
+    def want(reqs):
+        return [list(range(r.input_ids[0], r.input_ids[0] + r.max_new_tokens)) for r in reqs]
+    for k in (1, 2, 3):
+        eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(200), max_batch=3, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
+        cb = ContinuousBatcher(eng, eos_ids=(), chunk=4, prefetch=k)
+        reqs = [req(10, 8, 9, 20), req(20, 8, 5, 20), req(30, 8, 13, 20), req(40, 8, 6, 30), req(50, 8, 3), req(60, 8, 7, 20), req(70, 8, 4, 40), req(80, 8, 9, 10)]
+        out = cb.run(reqs)
+        assert [o.tolist() for o in out] == want(reqs), k
+        assert cb.idle and not eng.slots and not getattr(eng, "_pref", None)
+        kinds = [e[0] for e in eng.log]
+        assert kinds.count("prefetch") == kinds.count("take") >= 2
+        # every take is followed at once by the prefill of exactly the prefetched group
+        for i, e in enumerate(eng.log):
+            if e[0] == "take":
+                assert eng.log[i + 1][0] == "prefill"
+        # the first admission is the ordinary one (the engine is empty: its tower cannot be hidden behind anything)
+        assert kinds[0] == "vit" and kinds[1] == "prefill"
+        # towers run ahead of their admission: a prefetch is logged while slots are occupied, and decode chunks happen between prefetch and take
+        i0 = kinds.index("prefetch")
+        assert "decode" in kinds[i0:kinds.index("take", i0)]
+        # patches seen by prefetch + vit calls == all image patches, each exactly once
+        assert sum(e[1] for e in eng.log if e[0] in ("vit", "prefetch")) == sum(r.n_patches() for r in reqs)
+    # prefetch = 0 is today's behaviour: no prefetch calls at all
+    eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(200), max_batch=3, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
+    ContinuousBatcher(eng, eos_ids=(), chunk=4).run([req(10, 8, 9, 20), req(20, 8, 5, 20)])
+    assert not any(e[0] in ("prefetch", "take") for e in eng.log)

@@ -95,3 +95,23 @@ def test_prefetch_protocol_errors_and_mixing_with_the_synchronous_tower(world):
     assert fin[0] == 1 and fin[1] == 1
     assert eng.slot_read(0, 30).tolist() == ref[0][0].tolist() and eng.slot_read(1, 30).tolist() == ref[0][1].tolist()
     eng.slot_release(0); eng.slot_release(1)
+
+
+def test_scheduler_look_ahead_gives_the_same_tokens(world):
+    """ContinuousBatcher(prefetch = k): the towers of the next k queued requests run on the side stream beside the occupied slots (which then
+    decode on their CU partition, half-chip plan), the group is admitted with take + prefill only — same tokens as without look-ahead."""
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    cfg, eng = world
+    grids = [(1, 24, 32), (1, 8, 8), (1, 16, 16), (1, 40, 48), (1, 8, 12), (1, 32, 32), (1, 16, 24), (1, 24, 24), (1, 48, 48), (1, 8, 8), (1, 12, 16)]
+    caps = [70, 130, 5, 200, 64, 90, 33, 120, 150, 1, 77]
+    reqs = []
+    for i, (g, cap) in enumerate(zip(grids, caps)):
+        pv, grid, ids, lens = _batch(cfg, [g], 400 + i)
+        reqs.append((ids, pv, grid, cap))
+    mk = lambda dev: [Request(ids, torch.from_numpy(pv).cuda() if dev else pv, grid, cap) for ids, pv, grid, cap in reqs]
+    ref = ContinuousBatcher(eng, chunk=8).run(mk(False))
+    assert [len(r) for r in ref] == caps
+    for k, dev in ((1, False), (1, True), (3, True), (4, False)):
+        got = ContinuousBatcher(eng, chunk=8, prefetch=k).run(mk(dev))
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (k, dev)
+    assert eng.kv_pool_info()[0] == eng.kv_pool_info()[1]
