@@ -283,7 +283,8 @@ def main():
             for pr, g, n in zip(prompts, grids, n_patches):
                 reqs.append(Request(pr, pix[off:off + n], np.asarray([g], np.int64), a.max_new_tokens))
                 off += n
-            outs = ContinuousBatcher(eng, eos_ids=()).run(reqs)
+            # look-ahead: with EOS disabled and equal caps every slot finishes together, so the whole next group's towers are prefetched
+            outs = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", "0"))).run(reqs)
             out = np.zeros((len(outs), a.max_new_tokens), np.int32)
             out_lens = np.zeros(len(outs), np.int32)
             for i, o in enumerate(outs):
