@@ -1383,6 +1383,10 @@ int dots_slots_reset(DotsEngine* e) {
     if (!e->finalized) return e->fail(DOTS_E_STATE, "weights not finalized");
     CK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
+    if (e->pref_pending) {                               // a prefetched tower nobody took (an abandoned serving loop): drop it
+        if (!e->pref_deferred) CK(hipStreamWaitEvent(s, e->ev_vis_ready, 0));
+        e->pref_pending = e->pref_deferred = false;
+    }
     for (int b = 0; b < (int)e->slot_pages.size(); ++b) release_pages(e, b);
     CK(hipMemcpyAsync(e->block_table, e->hp_table.data(), e->hp_table.size() * 4, hipMemcpyHostToDevice, s));
     std::fill(e->slot_active, e->slot_active + DOTS_MAX_BATCH, 0);

@@ -191,23 +191,34 @@ class DotsOcrHipForCausalLM:
         if pipelined:
             pix, g, on_dev = pixels_of(plan[0])
             self.engine.vit_prefetch(pix, g, on_device=on_dev)
-        for k, sl in enumerate(plan):
-            lens = np.array([len(prompts[b]) for b in sl], np.int32)
-            packed = np.concatenate([prompts[b] for b in sl])
-            pix, g, on_dev = pixels_of(sl)
-            if pipelined:
-                self.engine.vit_take()
-                if k + 1 < len(plan):
-                    npix, ng, non_dev = pixels_of(plan[k + 1])
-                    self.engine.vit_prefetch(npix, ng, on_device=non_dev, after_prefill=True)
-                out, out_lens = self.engine.generate(packed, lens, max_new_tokens=max_new_tokens, eos_ids=eos, vision_taken=True)
-            elif pix is not None:
-                out, out_lens = self.engine.generate(packed, lens, pix, g, max_new_tokens, eos, on_dev)
-            else:
-                out, out_lens = self.engine.generate(packed, lens, None, None, max_new_tokens, eos)
-            for j, b in enumerate(sl):
-                new_tokens[b, :out_lens[j]] = out[j, :out_lens[j]]
-                n_max = max(n_max, int(out_lens[j]))
+        prefetched = pipelined                   # a tower is in flight / waiting to be taken
+        try:
+            for k, sl in enumerate(plan):
+                lens = np.array([len(prompts[b]) for b in sl], np.int32)
+                packed = np.concatenate([prompts[b] for b in sl])
+                pix, g, on_dev = pixels_of(sl)
+                if pipelined:
+                    self.engine.vit_take()
+                    prefetched = False
+                    if k + 1 < len(plan):
+                        npix, ng, non_dev = pixels_of(plan[k + 1])
+                        self.engine.vit_prefetch(npix, ng, on_device=non_dev, after_prefill=True)
+                        prefetched = True
+                    out, out_lens = self.engine.generate(packed, lens, max_new_tokens=max_new_tokens, eos_ids=eos, vision_taken=True)
+                elif pix is not None:
+                    out, out_lens = self.engine.generate(packed, lens, pix, g, max_new_tokens, eos, on_dev)
+                else:
+                    out, out_lens = self.engine.generate(packed, lens, None, None, max_new_tokens, eos)
+                for j, b in enumerate(sl):
+                    new_tokens[b, :out_lens[j]] = out[j, :out_lens[j]]
+                    n_max = max(n_max, int(out_lens[j]))
+        except Exception:
+            if prefetched:                           # leave the engine usable: a waiting prefetch would refuse the next one
+                try:
+                    self.engine.vit_take()
+                except Exception:
+                    pass
+            raise
         full = np.concatenate([ids.astype(np.int64), new_tokens[:, :n_max]], axis=1)    # HF stops at the longest sequence
         res = torch.from_numpy(full)
         return res.to(input_ids.device) if input_ids.is_cuda else res

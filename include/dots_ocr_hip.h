@@ -173,7 +173,8 @@ int dots_set_decode_flow(DotsEngine* e, int mode);
  * slots keep decoding.  Any static-batch call (dots_prefill / dots_generate) resets every slot.
  *
  * dots_slots_reset   enter slot mode with every slot free and every KV page back in the pool (a serving loop calls it once at start:
- *                    the pages of an earlier static batch would otherwise count as used until the first dots_slots_prefill).
+ *                    the pages of an earlier static batch would otherwise count as used until the first dots_slots_prefill); a prefetched
+ *                    vision batch that was never taken is dropped.
  * dots_set_eos       stop tokens for the slot calls.
  * dots_slots_prefill n new sequences (packed ids, like dots_prefill) into the free slots `slots[i]`, each with its own
  *                    cap on generated tokens; if the prompts hold image tokens, run dots_vit_forward for exactly these

@@ -95,6 +95,12 @@ def test_prefetch_protocol_errors_and_mixing_with_the_synchronous_tower(world):
     assert fin[0] == 1 and fin[1] == 1
     assert eng.slot_read(0, 30).tolist() == ref[0][0].tolist() and eng.slot_read(1, 30).tolist() == ref[0][1].tolist()
     eng.slot_release(0); eng.slot_release(1)
+    # an abandoned prefetch does not wedge the engine: slots_reset drops it
+    eng.vit_prefetch(pv, grid)
+    eng.slots_reset()
+    eng.vit_prefetch(pv, grid)
+    eng.vit_take()
+    assert np.array_equal(eng.generate(ids, lens, max_new_tokens=30, vision_taken=True)[0], ref[0])
 
 
 def test_scheduler_look_ahead_gives_the_same_tokens(world):
