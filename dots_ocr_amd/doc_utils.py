@@ -3,7 +3,7 @@
 
 The reference renders with PyMuPDF (`fitz`).  When it is importable it is used, exactly as the reference does.  When it is not
 (this image), a built-in rasteriser handles the documents an OCR pipeline is fed most: IMAGE-ONLY PDFs — scans — whose pages
-paint one or more image XObjects (DCTDecode / FlateDecode [+ PNG predictors] / raw; DeviceRGB, DeviceGray, DeviceCMYK, Indexed;
+paint one or more image XObjects (DCTDecode / CCITTFaxDecode / FlateDecode [+ PNG predictors] / raw; DeviceRGB, DeviceGray, DeviceCMYK, Indexed;
 classic xref tables, object streams and compressed xrefs) placed with `cm` matrices; an invisible OCR text layer (render mode 3) is
 ignored as it is invisible.  A page with visible text or vector painting is refused with PdfContentNotSupported instead of being
 rendered wrongly.  Same names, arguments and dpi rules as the reference either way.
@@ -208,6 +208,40 @@ def _png_unpredict(data: bytes, columns: int, colors: int, bpc: int) -> bytes:
     return bytes(out)
 
 
+def _ccitt_image(data: bytes, parms: dict, width: int, height: int, get) -> Image.Image:
+    """CCITTFaxDecode stream -> PIL image, by wrapping the fax data in a one-strip TIFF (Pillow's libtiff decodes Group 3 / 4).
+    PDF semantics (ISO 32000-1 Table 11): the decoder writes 1 for a black run when BlackIs1, else 0; in DeviceGray a 1 bit is white.
+    libtiff writes 1 for a black run, so Photometric = BlackIsZero reproduces BlackIs1 = true and WhiteIsZero the default."""
+    import struct
+    from PIL import features
+    if not features.check("libtiff"):
+        raise PdfContentNotSupported("CCITT fax images need Pillow with libtiff")
+    k = int(get(parms.get("K", 0)) or 0)
+    cols = int(get(parms.get("Columns", 1728)) or 1728)
+    rows = int(get(parms.get("Rows", 0)) or 0) or height
+    black_is_1 = bool(get(parms.get("BlackIs1", False)))
+    if get(parms.get("EncodedByteAlign", False)) and k < 0:
+        raise PdfContentNotSupported("byte-aligned Group 4 fax data")
+    tags = [(256, 4, cols), (257, 4, rows), (258, 3, 1), (259, 3, 4 if k < 0 else 3), (262, 3, 1 if black_is_1 else 0), (266, 3, 1),
+            (273, 4, 0), (277, 3, 1), (278, 4, rows), (279, 4, len(data))]
+    if k >= 0:
+        tags.append((292, 4, (1 if k > 0 else 0) | (4 if get(parms.get("EncodedByteAlign", False)) else 0)))
+    tags.sort()
+    ifd_len = 2 + 12 * len(tags) + 4
+    strip_off = 8 + ifd_len
+    out = bytearray(b"II*\x00" + struct.pack("<I", 8) + struct.pack("<H", len(tags)))
+    for tag, typ, val in tags:
+        if tag == 273:
+            val = strip_off
+        out += struct.pack("<HHI", tag, typ, 1) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+    out += struct.pack("<I", 0) + data
+    im = Image.open(io.BytesIO(bytes(out)))
+    im.load()
+    if im.size != (width, height):
+        im = im.crop((0, 0, width, height))
+    return im
+
+
 class PdfDocument:
     """Just enough of a PDF reader to walk the page tree and fetch image XObjects."""
 
@@ -287,8 +321,8 @@ class PdfDocument:
             elif f in ("ASCII85Decode", "A85"):
                 import base64
                 raw = base64.a85decode(raw.strip().removesuffix(b"~>").removeprefix(b"<~") if hasattr(bytes, "removesuffix") else raw, adobe=False)
-            elif f in ("DCTDecode", "DCT", "JPXDecode"):
-                break                                     # image codec: left to PIL
+            elif f in ("DCTDecode", "DCT", "JPXDecode", "CCITTFaxDecode", "CCF"):
+                break                                     # image codec: left to PIL (image())
             else:
                 raise PdfContentNotSupported(f"stream filter {f}")
         return raw
@@ -323,11 +357,17 @@ class PdfDocument:
         last = self.get(filters[-1]) if filters else None
         data = self.stream(num)
         if last in ("DCTDecode", "DCT", "JPXDecode"):
-            im = Image.open(io.BytesIO(data))
+            im = Image.open(io.BytesIO(data))             # (Pillow undoes the inversion of Adobe CMYK JPEGs itself)
             im.load()
-            if im.mode == "CMYK":                         # Adobe JPEGs store inverted CMYK
+            return im.convert("RGB")
+        if last in ("CCITTFaxDecode", "CCF"):             # bilevel scans: Group 3 / Group 4 fax coding
+            parms = self.get(dic.get("DecodeParms"))
+            parms = self.get(parms[-1]) if isinstance(parms, list) else parms
+            im = _ccitt_image(data, parms or {}, w, h, self.get)
+            dec = self.get(dic.get("Decode"))
+            if isinstance(dec, list) and len(dec) == 2 and float(self.get(dec[0])) > float(self.get(dec[1])):
                 from PIL import ImageChops
-                im = ImageChops.invert(im) if dic.get("Decode") else im
+                im = ImageChops.invert(im.convert("L"))
             return im.convert("RGB")
         if self.get(dic.get("ImageMask")):
             raise PdfContentNotSupported("stencil image masks")

@@ -620,3 +620,42 @@ def test_continuous_batcher_look_ahead_prefetches_the_next_towers_with_a_fake_en
     eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(200), max_batch=3, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
     ContinuousBatcher(eng, eos_ids=(), chunk=4).run([req(10, 8, 9, 20), req(20, 8, 5, 20)])
     assert not any(e[0] in ("prefetch", "take") for e in eng.log)
+
+
+def test_pdf_rasteriser_colour_modes_rotation_and_several_images_per_page():
+    """What scanners really produce: gray / RGB / CMYK JPEG, bilevel Group-4 fax (CCITTFaxDecode), palette images; a /Rotate 90 page;
+    a page assembled from two image strips."""
+    import io
+    import zlib
+    from PIL import Image, ImageDraw
+    from dots_ocr_amd import doc_utils as du
+    base = Image.new("RGB", (400, 300), (255, 255, 255))
+    d = ImageDraw.Draw(base)
+    d.rectangle([50, 40, 300, 200], fill=(200, 30, 30))
+    d.text((60, 220), "hello scanned world", fill=(0, 0, 0))
+    for mode, tol in (("L", 0.5), ("1", 0.0), ("P", 0.0), ("CMYK", 0.5), ("RGB", 1.5)):
+        im = base.convert(mode)
+        buf = io.BytesIO()
+        im.save(buf, "PDF", resolution=72.0)
+        out = du.fitz_doc_to_image(du.PdfDocument(buf.getvalue())[0], target_dpi=72)
+        assert out.size == (400, 300) and out.mode == "RGB"
+        assert np.abs(np.asarray(out, np.int16) - np.asarray(im.convert("RGB"), np.int16)).mean() <= tol, mode
+
+    def raw_image(arr):                                   # uncompressed-then-deflated 8-bit RGB image XObject
+        raw = zlib.compress(arr.tobytes())
+        return (b"<< /Type /XObject /Subtype /Image /Width %d /Height %d /ColorSpace /DeviceRGB /BitsPerComponent 8 /Filter /FlateDecode /Length %d >>"
+                % (arr.shape[1], arr.shape[0], len(raw)), raw)
+    top = np.zeros((100, 200, 3), np.uint8); top[..., 0] = 250
+    bot = np.zeros((50, 200, 3), np.uint8); bot[..., 2] = 250
+    content = b"q 200 0 0 100 0 50 cm /T Do Q q 200 0 0 50 0 0 cm /B Do Q"
+    objs = {
+        1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+        2: (b"<< /Type /Pages /Kids [3 0 R] /Count 1 >>", None),
+        3: (b"<< /Type /Page /Parent 2 0 R /MediaBox [0 0 200 150] /Rotate 90 /Resources << /XObject << /T 4 0 R /B 6 0 R >> >> /Contents 5 0 R >>", None),
+        4: raw_image(top), 5: (b"<< /Length %d >>" % len(content), content), 6: raw_image(bot),
+    }
+    page = np.asarray(du.fitz_doc_to_image(du.PdfDocument(_pdf(objs))[0], target_dpi=72))
+    assert page.shape == (200, 150, 3)                    # rotated clockwise by 90 degrees
+    upright = np.rot90(page, 1)                           # undo: counter-clockwise
+    assert (upright[:100, :, 0] == 250).all() and (upright[:100, :, 2] == 0).all()        # red strip on top
+    assert (upright[100:, :, 2] == 250).all() and (upright[100:, :, 0] == 0).all()        # blue strip below
