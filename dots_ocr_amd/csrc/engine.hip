@@ -647,12 +647,32 @@ hipError_t attn_event(DotsEngine* e, int idx) {
 }
 
 // Runs on e->vs (the main stream, or s_vit for a prefetch); the merged rows go to `vis_out`.
+// Everything vit_forward can refuse, checked without touching the device: a prefetch whose launch is deferred behind a prefill
+// (dots_vit_prefetch, after_prefill) is validated when it is REQUESTED, so that it cannot fail inside that prefill after the slots
+// have been marked occupied.
+int check_vision_request(DotsEngine* e, int64_t N, const int64_t* grid, int n_img) {
+    const DotsConfig& c = e->cfg;
+    const int m = c.v_merge;
+    if (N > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches %lld > max_patches %lld", (long long)N, (long long)e->P);
+    if (c.v_temporal_patch != 1) return e->fail(DOTS_E_INVALID, "temporal_patch_size != 1 is not supported");
+    int64_t off = 0, n_seq = 0;
+    for (int i = 0; i < n_img; ++i) {
+        const int64_t t = grid[i * 3], h = grid[i * 3 + 1], w = grid[i * 3 + 2];
+        if (t < 1 || h < 1 || w < 1 || h % m || w % m) return e->fail(DOTS_E_INVALID, "grid_thw[%d] not divisible by merge size", i);
+        if (t * h * w > N - off) return e->fail(DOTS_E_INVALID, "grid_thw does not match total_patches");
+        off += t * h * w;
+        n_seq += t;
+    }
+    if (off != N) return e->fail(DOTS_E_INVALID, "grid_thw covers %lld patches, total_patches is %lld", (long long)off, (long long)N);
+    if (n_seq > 256) return e->fail(DOTS_E_CAPACITY, "more than 256 images per call");
+    return DOTS_OK;
+}
+
 int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* grid, int n_img, void* out_dev, bf16_t* vis_out, int64_t* rows_out) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->vs;
     const int E = c.v_embed_dim, Hh = c.v_heads, m = c.v_merge;
-    if (N > e->P) return e->fail(DOTS_E_CAPACITY, "total_patches %lld > max_patches %lld", (long long)N, (long long)e->P);
-    if (c.v_temporal_patch != 1) return e->fail(DOTS_E_INVALID, "temporal_patch_size != 1 is not supported");
+    RET(check_vision_request(e, N, grid, n_img));
     // ---- host: position ids (block-major over merge x merge groups), sequences
     e->h_pos.resize((size_t)N * 2);
     std::vector<int> lens;
@@ -1227,6 +1247,7 @@ int dots_vit_prefetch(DotsEngine* e, const float* pixel_values, int on_device, i
     if (!pixel_values || !grid_thw || n_img < 1 || total_patches < 1) return e->fail(DOTS_E_INVALID, "bad vit_prefetch arguments");
     if (e->pref_pending) return e->fail(DOTS_E_STATE, "a prefetched vision batch is waiting: dots_vit_take_prefetched first");
     CK(hipSetDevice(e->device));
+    RET(check_vision_request(e, total_patches, grid_thw, n_img));          // now, not when the deferred tower is launched inside a prefill
     RET(ensure_overlap_streams(e));
     const float* pix = nullptr;
     RET(stage_pixels(e, e->stream, pixel_values, on_device, total_patches, &pix));      // host pixels: staged on the main stream, now
@@ -1421,18 +1442,26 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     // context capacity (an admission policy that leaves head-room makes this rare: dots_ocr_amd/scheduler.py).
     for (int b = 0; b < rows; ++b) {
         if (!e->slot_active[b] || e->slot_done[b]) continue;
-        const int want = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b]);
+        // A step at context c writes KV position c and brings the sequence to c + 2 tokens, so n_steps more steps need positions
+        // [0, ctx + n_steps), and a sequence limited to slot_limit tokens never writes beyond position slot_limit - 2.
+        const int want = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b] - 1);
         bool changed = false;
         const int have = grow_pages(e, b, want, &changed);
         if (changed) CK(upload_table_row(e, b));
         if (have < want) {
-            e->slot_limit[b] = have;
-            const int32_t cap = have - e->slot_prompt[b];                 // >= tokens generated so far: the pages cover the current context
+            // Positions [0, have) exist: the last step the row may take is the one at context have - 1, which leaves it with have + 1
+            // tokens.  commit_token finishes a row when a step brings it to its cap — so a row that already sits AT context `have`
+            // (the pool ran dry exactly on its page boundary) must be stopped here: its next step would write position
+            // `have` through a block-table entry it does not own (the scratch page every idle row writes) and read it back.
+            e->slot_limit[b] = have + 1;
+            const int32_t cap = have + 1 - e->slot_prompt[b];               // generated tokens; >= the tokens generated so far
+            static const int32_t one = 1;
             CK(hipMemcpyAsync(e->d_max_len + b, &cap, 4, hipMemcpyHostToDevice, s));
+            if (have <= e->slot_ctx_ub[b]) CK(hipMemcpyAsync(e->finished + b, &one, 4, hipMemcpyHostToDevice, s));
             CK(hipStreamSynchronize(s));                                     // `cap` is a stack variable
             e->kv_capped += 1;
         }
-        e->slot_ctx_ub[b] = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b]);
+        e->slot_ctx_ub[b] = std::min(e->slot_ctx_ub[b] + n_steps, e->slot_limit[b] - 1);
     }
     const int n_splits = splits_for_ctx(e->cfg.max_seq_len);
     e->B = rows;

@@ -36,10 +36,14 @@ class Request:
 class ContinuousBatcher:
     """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
 
-    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: int = 2, prefetch: int = 0):
+    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: Optional[int] = 2, prefetch: int = 0):
         self.engine = engine
         self.chunk = max(1, int(chunk))
-        self.headroom_pages = max(0, int(headroom_pages))       # free KV pages kept per running sequence when admitting (see plan_admission)
+        # free KV pages kept per running sequence when admitting (see plan_admission).  None = FULL RESERVATION: a sequence is admitted only
+        # when the pool could hold prompt + max_new_tokens of every running sequence and of this one, so nothing is ever truncated by a dry
+        # pool (the policy of rounds 1-2; fewer sequences in flight when caps are generous, as with the reference's max_new_tokens=24000).
+        self.full_reservation = headroom_pages is None
+        self.headroom_pages = 0 if headroom_pages is None else max(0, int(headroom_pages))
         # look-ahead: the vision tower of the next `prefetch` queued requests runs on the engine's CU-masked side stream while the
         # occupied slots keep decoding on the other CU partition (Engine.vit_prefetch); that group is then admitted as a whole — prefill
         # only, no tower in the decode loop's way — as soon as it has the slots and pages.  1 suits requests that finish at different
@@ -56,6 +60,7 @@ class ContinuousBatcher:
         self._next_id = 0
         self.decode_steps = 0
         self.admissions = 0
+        self.kv_truncated = 0                                    # sequences ended early by a dry KV pool (finish reason "kv_pool_exhausted")
         engine.set_eos(list(eos_ids))
         if hasattr(engine, "slots_reset"):           # start from an empty engine: no occupied slot, every KV page in the pool
             engine.slots_reset()                     # (a static batch or a failed run may have left both behind)
@@ -114,6 +119,12 @@ class ContinuousBatcher:
             # at what its pages hold — stays the exception.  Nothing running: admit whatever fits (submit() checked that it can).
             need = self._admit_pages(t, req.max_new_tokens)
             reserve = self.headroom_pages * (len(self.running) + len(group) + 1) if (self.running or group) else 0
+            if self.full_reservation:                # worst case of everything in flight must fit the pool
+                total = self.engine.kv_pool_info()[0] if hasattr(self.engine, "kv_pool_info") else 1 << 30
+                worst = lambda r: (min(int(r.input_ids.shape[0]) + int(r.max_new_tokens), self.max_seq_len) + 63) // 64
+                committed = sum(worst(r) for _, r in self.running.values()) + sum(worst(r) for _, _, r in group)
+                if (self.running or group) and committed + worst(req) > total:
+                    break
             if need + reserve > pages_free:
                 break                                                                    # wait for a running sequence to return its pages
             pages_free -= need
@@ -166,8 +177,16 @@ class ContinuousBatcher:
             reserve = self.headroom_pages * (len(self.running) + len(self._ahead)) if self.running else 0
             if need + reserve > self.engine.kv_pool_info()[1]:
                 return False
-        self.engine.vit_take()
-        self._prefill([(free[i], rid, r) for i, (rid, r) in enumerate(self._ahead)])
+        group = self._ahead
+        try:
+            self.engine.vit_take()
+            self._prefill([(free[i], rid, r) for i, (rid, r) in enumerate(group)])
+        except Exception:
+            # the rows are gone (or were never there): the group goes back to the head of the queue so that the caller's failure
+            # handling — which walks `pending` and `running` — sees its requests, and the next step does not take a stale batch
+            self._ahead, self._ahead_keep = [], None
+            self.pending.extendleft(reversed(group))
+            raise
         self._ahead, self._ahead_keep = [], None
         return True
 
@@ -188,8 +207,12 @@ class ContinuousBatcher:
             patches, tokens, pages = patches + p, tokens + t, pages + pg
         if not group:
             return
-        pv, grid, on_dev, keep = self._pixels(group)
-        self.engine.vit_prefetch(pv, grid, on_device=on_dev)
+        try:
+            pv, grid, on_dev, keep = self._pixels(group)
+            self.engine.vit_prefetch(pv, grid, on_device=on_dev)
+        except Exception:
+            self.pending.extendleft(reversed(group))     # nothing was prefetched: the requests keep their place in the queue
+            raise
         self._ahead, self._ahead_keep = group, keep
 
     # ------------------------------------------------------------------ main loop
@@ -199,7 +222,15 @@ class ContinuousBatcher:
         for s in sorted(self.running):
             if fin[s] == 1:
                 rid, req = self.running.pop(s)
-                done.append((rid, req, self.engine.slot_read(s, int(lens[s]))))
+                toks = self.engine.slot_read(s, int(lens[s]))
+                # a sequence the engine ended early because the KV pool ran dry (its cap was lowered to what its pages hold) is not an
+                # ordinary "length" stop: say so on the request, count it, let the server report it
+                req.kv_truncated = False
+                if hasattr(self.engine, "slot_capacity"):
+                    _, limit = self.engine.slot_capacity(s)
+                    req.kv_truncated = bool(limit < int(req.input_ids.shape[0]) + int(req.max_new_tokens) and len(toks) >= limit - int(req.input_ids.shape[0]))
+                    self.kv_truncated += int(req.kv_truncated)
+                done.append((rid, req, toks))
                 self.engine.slot_release(s)
         return done
 
@@ -221,7 +252,7 @@ class ContinuousBatcher:
             if self._ahead:                          # nothing runs, so every slot and page is free: the group fits by construction
                 raise RuntimeError("a prefetched group could not be admitted into an empty engine")
             if self.pending:                         # nothing runs, nothing could be admitted: it never will be
-                rid, req = self.pending.popleft()
+                rid, req = self.pending[0]           # left in the queue: whoever handles the error finds (and fails) it there
                 raise RuntimeError(f"request {rid} ({req.input_ids.shape[0]} prompt tokens, {req.n_patches()} patches) cannot be admitted "
                                    f"into an empty engine (KV pool {self.engine.kv_pool_info() if hasattr(self.engine, 'kv_pool_info') else '?'})")
             return []

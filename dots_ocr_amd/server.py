@@ -120,12 +120,14 @@ class ContinuousWorker(BatchingWorker):
     def _key(j: _Job):
         return (j.temperature, j.top_p)
 
-    def _finish(self, job: _Job, prompt_tokens: int, toks):
+    def _finish(self, job: _Job, prompt_tokens: int, toks, kv_truncated: bool = False):
         eos = set(self.model.config.eos_token_ids)
         toks = [int(t) for t in toks]
         text = self.processor.batch_decode([toks], skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
-        job.future.set_result({"text": text, "prompt_tokens": prompt_tokens, "completion_tokens": len(toks),
-                               "finish_reason": "stop" if toks and toks[-1] in eos else "length"})
+        # "kv_pool_exhausted": the engine ended the sequence at what its KV pages hold (vLLM would preempt and recompute; here the
+        # caller sees that the output is short for a reason other than max_tokens and can resubmit)
+        reason = "stop" if toks and toks[-1] in eos else ("kv_pool_exhausted" if kv_truncated else "length")
+        job.future.set_result({"text": text, "prompt_tokens": prompt_tokens, "completion_tokens": len(toks), "finish_reason": reason})
 
     def _run(self):
         from collections import deque
@@ -172,12 +174,12 @@ class ContinuousWorker(BatchingWorker):
                         job.future.set_exception(e)
                 if cb is not None and not cb.idle:
                     for _, req, toks in cb.step():
-                        self._finish(req.tag, int(req.input_ids.shape[0]), toks)
+                        self._finish(req.tag, int(req.input_ids.shape[0]), toks, getattr(req, "kv_truncated", False))
                     if admitted:
                         self.batches.append(len(cb.running))
             except Exception as e:                                   # engine failure: fail everything in flight, start clean
                 if cb is not None:
-                    for _, (_, req) in list(cb.running.items()) + [(None, p) for p in cb.pending]:
+                    for _, req in list(cb.running.values()) + list(cb.pending) + list(cb._ahead):
                         if not req.tag.future.done():
                             req.tag.future.set_exception(e)
                 cb, key = None, None
