@@ -28,6 +28,7 @@
 // with the explicit LDS look-ahead of the MFMA block: 1099 -> 1163 TFLOP/s (same-box A/B, profiles/r01_final2_*);
 // either change alone gains nothing.  Bit-identical results (same accumulation order).
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -326,6 +327,274 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the bidirectional (ViT) kernel as 4 waves x 64 query rows — ONE wave per SIMD owning the whole 512-register file.
+// Why: with two 32-row waves per SIMD every MFMA needs its own LDS fragment (32 ds_read_b128 per 32 MFMAs), the K/V
+// tiles are staged through registers (8 ds_write_b128 per thread and tile) and a wave's 32-MFMA block took 1 860 cycles instead of
+// 1 024.  Here a wave holds TWO 32-row query blocks (A, B): every K / V^T fragment feeds two MFMAs, the tiles arrive by LDS-DMA
+// (buffer_load ... lds: no staging registers, no ds_write), ONE barrier per tile, and the softmax is spread instruction by
+// instruction over the gaps of a 64-MFMA stream that does not depend on it.  tools/mfma_filler_probe.hip measured what a gap holds
+// with one wave per SIMD: 4 VALU instructions behind an MFMA are free (32-33 cycles per MFMA), the 5th costs 4 cycles, 7 cost 14 —
+// whatever the register files of the MFMA's operands; and EVERY instruction (SALU, waits, nops, LDS, DMA) takes a slot.
+//   tile j:   gaps  0- 7   S(j+1) = K(j+1).Q^T, k steps 0-1            || row maxima of S(j): 4 v_max3 per gap
+//             [rare, out of line: mask of a ragged tile; rescale of O and l — O is complete through tile j-1, nothing is pending]
+//             gaps  8-31   S(j+1), k steps 2-7                         || P(j) = exp2(S(j) c - m), row sums: 14 instructions per 3 gaps,
+//             gaps 32-55   O += V^T(j).P(j), key slabs 0-2             ||   key slab by key slab, each one ready before its product starts
+//             gaps 56-63   O += V^T(j).P(j), key slab 3
+// Register plan (hipcc left alone keeps every MFMA result in the accumulator file and copies all 64 scores out before the first MFMA
+// of the next phase; it also hoists / sinks plain arithmetic over scheduling barriers): the MFMAs and their fillers are `asm
+// volatile`, one statement per gap.  S(j), S(j+1) live in arch VGPRs (VGPR-form MFMA), where the softmax reads them in place; Q is
+// the AGPR B operand of the score MFMAs and never occupies an arch VGPR; O is an AGPR accumulator.  AGPRs: O 128 + Q 64; VGPRs:
+// S 2 x 64, P 32, fragments 16, ~35 others.
+// Hazards (nothing inside an asm string is padded by the compiler): a transcendental's result is used two instructions later at the
+// earliest; a score read by the softmax was written >= 32 MFMAs earlier; a P word is read by an MFMA >= 1 MFMA after the
+// v_cvt_pk that wrote it; MFMAs on the same accumulator are >= 3 MFMAs apart; the A operand of an MFMA comes from LDS (the compiler
+// places the lgkmcnt wait in front of the statement that uses it).
+// LDS: K ring 3 x 16 KiB (tiles j+1 .. j+3), V^T ring 4 x 16 KiB (tiles j .. j+3), swizzles as in the 8-wave kernel but applied on
+// the DMA source side (LDS-DMA writes lane-linear).  Tile j+3 is requested during tile j: two tile periods of cover.  K rows past a
+// sequence's end are read from the 64 spare rows the K buffer carries (kernels.h) and masked.
+constexpr int K_RING = 3, V_RING = 4;
+constexpr int RING_BYTES = (K_RING + V_RING) * KT_BYTES;      // KT_BYTES == VT_BYTES == 16 KiB
+
+#define F64_MFMA_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], 0\n\t"
+#define F64_MFMA_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
+#define F64_MAX4 "v_max3_f32 %[mx], %[mx], %[x0], %[x1]\n\tv_max3_f32 %[mx], %[mx], %[x2], %[x3]\n\tv_max3_f32 %[mx], %[mx], %[x4], %[x5]\n\tv_max3_f32 %[mx], %[mx], %[x6], %[x7]"
+// exp stream of two pairs X, Y over three gaps (5 + 5 + 4 instructions)
+#define F64_EXP_A "v_fma_f32 %[t0], %[x0], %[sc], %[nm]\n\tv_fma_f32 %[t1], %[x1], %[sc], %[nm]\n\tv_exp_f32_e32 %[t0], %[t0]\n\tv_exp_f32_e32 %[t1], %[t1]\n\tv_add_f32_e32 %[ps], %[ps], %[t0]"
+#define F64_EXP_B "v_add_f32_e32 %[ps], %[ps], %[t1]\n\tv_cvt_pk_bf16_f32 %[wx], %[t0], %[t1]\n\tv_fma_f32 %[u0], %[y0], %[sc], %[nm]\n\tv_fma_f32 %[u1], %[y1], %[sc], %[nm]\n\tv_exp_f32_e32 %[u0], %[u0]"
+#define F64_EXP_C "v_exp_f32_e32 %[u1], %[u1]\n\tv_add_f32_e32 %[ps], %[ps], %[u0]\n\tv_add_f32_e32 %[ps], %[ps], %[u1]\n\tv_cvt_pk_bf16_f32 %[wy], %[u0], %[u1]"
+
+// compile-time loop: the gap index must be a constant expression (operand selection by `if constexpr`, never by run-time selects)
+template <int... I, class F> DEVI void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> DEVI void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__global__ __launch_bounds__(256) void flash_attn64_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
+    bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
+    float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring | V^T ring
+    const QBlock qb = blocks[xcd_remap(blockIdx.x, n_items)];
+    const int h = qb.head, hkv = h / group, n = qb.n;
+    const int tid = threadIdx.x, l = tid & 63, l31 = l & 31, hi = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (n + 63) >> 6;
+    const int t_last = n_tiles - 1;
+
+    // ---- Q fragments of the two blocks: B operand, lane (q, hi) holds Q[q][16 ks + 8 hi .. +7]
+    bf16x8 qf[2][8];
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk) {
+        const int qrow = qb.q0 + w * 64 + bk * 32 + l31;
+        const bf16_t* qp = Q + ((size_t)h * T + qb.tok0 + min(qrow, n - 1)) * 128 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[bk][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+    // ---- LDS-DMA (buffer_load ... lds): wave w copies K pieces 4i + w (keys 4p .. 4p+3, 256 B each) and V^T pieces 4i + w (d rows
+    // 8p .. 8p+7, 128 B each).  Keys / d rows advance by 16 / 32 per i, which leaves the swizzle terms unchanged: ONE per-lane source
+    // offset per operand; tile and piece enter through the scalar offset of the instruction, so a piece costs no VALU.
+    const int key0w = 4 * w + (l >> 4), d0w = 8 * w + (l >> 3);
+    const int k_src = key0w * 256 + (((l & 15) ^ (key0w & 15)) << 4);
+    const int v_src = (int)((size_t)d0w * Tpad * 2) + (((l & 7) ^ ((d0w >> 1) & 7)) << 4);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + ((size_t)hkv * T + qb.tok0) * 128), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VT + (size_t)hkv * 128 * Tpad + qb.pad0), 0, 0x7ffffff0, 0x00020000);
+    const int v_step = (int)(64 * Tpad);                          // bytes between d rows 32 apart
+    auto dma_piece = [&](int t, int kst, int vst, int i) {       // piece i of tile t: 0-3 K, 4-7 V^T
+        if (i < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + kst * KT_BYTES + (4 * i + w) * 1024), 16, k_src,
+                                                     (t * 64 + 16 * i) * 256, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + (K_RING + vst) * KT_BYTES + (4 * (i - 4) + w) * 1024), 16,
+                                                     v_src, t * 128 + (i - 4) * v_step, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_piece(min(t, t_last), t, t, i);
+
+    f32x16 o[2][4];
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[bk][dt][r] = 0.f;
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+    // fragment gather offsets: ((2 ks + hi) ^ (key & 15)) << 4 splits bitwise into a per-lane constant and ks << 5 — ONE register per
+    // operand; a fragment address is (lane constant + ring stage) ^ (ks << 5) (+ 8 KiB / 4 KiB steps as immediates)
+    const int k_lane = l31 * 256 + ((((l31 & 15) >> 1) << 5) | ((hi ^ (l31 & 1)) << 4));
+    const int vsw = (l31 >> 1) & 7;
+    const int v_lane = l31 * 128 + (((vsw >> 1) << 5) | ((hi ^ (vsw & 1)) << 4));
+    auto frag = [&](int base, int x, int imm) { return *reinterpret_cast<const bf16x8*>(smem + ((base ^ (x << 5)) + imm)); };
+
+    // ring positions: K(j+1), V^T(j), and the stages tile j+3 goes to
+    int k_cur = 1, v_cur = 0, k_dma = 0, v_dma = 3;
+    auto adv = [&](int& x, int ring) { x = x + 1 == ring ? 0 : x + 1; };
+
+    // ---- prologue: S(0)
+    f32x16 sA[2][2], sB[2][2];                                   // S(j) / S(j+1): two VGPR sets, swapped every tile
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // Q and tile 0 (requested first) are in; tiles 1, 2 may fly
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 f0 = frag(k_lane, ks, 0), f1 = frag(k_lane, ks, 8192);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (ks == 0) asm volatile(F64_MFMA_S0 : [d] "=&v"(sA[q4 & 1][q4 >> 1]) : [a] "v"(q4 >> 1 ? f1 : f0), [b] "a"(qf[q4 & 1][0]));
+            else asm volatile(F64_MFMA_S : [d] "+v"(sA[q4 & 1][q4 >> 1]) : [a] "v"(q4 >> 1 ? f1 : f0), [b] "a"(qf[q4 & 1][ks]));
+        }
+    }
+
+    // one tile: sc = S(j) (complete), sn <- S(j+1)
+    auto tile_body = [&](int j, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
+        // every wave's pieces of tile j+1 have landed (tile j+2's 8 may still fly) and every wave is done with the stages tile j+3 overwrites
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int t_dma = min(j + 3, t_last);
+        const int kl = k_lane + k_cur * KT_BYTES, vl = v_lane + (K_RING + v_cur) * KT_BYTES;
+        bf16x8 fa[2][2];                                          // fragment pairs, one step ahead
+        fa[0][0] = frag(kl, 0, 0);
+        fa[0][1] = frag(kl, 0, 8192);
+        // ---- gaps 0-7: score MFMAs of k steps 0, 1 || row maxima of S(j)
+        float mx[2] = {-INFINITY, -INFINITY};
+        static_for<8>([&sn, &sc, &mx, &qf, &fa, &frag, kl](auto gc) {   // explicit captures: clang does not capture a variable that is used by asm operands only
+            constexpr int g = decltype(gc)::value;
+            constexpr int ks = g >> 2, q4 = g & 3, bk = q4 & 1, tt = q4 >> 1, cur = ks & 1;
+            if constexpr (q4 == 0) { fa[cur ^ 1][0] = frag(kl, ks + 1, 0); fa[cur ^ 1][1] = frag(kl, ks + 1, 8192); }
+            constexpr int mb = g >> 2, mt = (g >> 1) & 1, r0 = 8 * (g & 1);          // 8 scores of block mb
+            const f32x16& xs = sc[mb][mt];
+            if constexpr (ks == 0)
+                asm volatile(F64_MFMA_S0 F64_MAX4 : [d] "=&v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][0]), [x0] "v"(xs[r0]), [x1] "v"(xs[r0 + 1]), [x2] "v"(xs[r0 + 2]), [x3] "v"(xs[r0 + 3]),
+                               [x4] "v"(xs[r0 + 4]), [x5] "v"(xs[r0 + 5]), [x6] "v"(xs[r0 + 6]), [x7] "v"(xs[r0 + 7]));
+            else
+                asm volatile(F64_MFMA_S F64_MAX4 : [d] "+v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [x0] "v"(xs[r0]), [x1] "v"(xs[r0 + 1]), [x2] "v"(xs[r0 + 2]), [x3] "v"(xs[r0 + 3]),
+                               [x4] "v"(xs[r0 + 4]), [x5] "v"(xs[r0 + 5]), [x6] "v"(xs[r0 + 6]), [x7] "v"(xs[r0 + 7]));
+        });
+        // ---- the product of tile j-1 is complete: mask of a ragged tile, rescale — both rare
+        const int key0 = j * 64;
+        if (key0 + 64 > n) {
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) {
+                float mm = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        sc[bk][t][r] = key < n ? sc[bk][t][r] : -INFINITY;
+                        mm = fmaxf(mm, sc[bk][t][r]);
+                    }
+                mx[bk] = mm;                                      // rows past the end hold whatever the spare K rows held: out of the maximum
+            }
+        }
+        const float c0 = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64)) * scale_log2e, c1 = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64)) * scale_log2e;
+        if (!__all(c0 - m_run[0] <= RESCALE_THR && c1 - m_run[1] <= RESCALE_THR)) {
+            const float cc[2] = {c0, c1};
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) {
+                const float m_new = fmaxf(m_run[bk], cc[bk]);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[bk] - m_new);
+                m_run[bk] = m_new;
+                l_run[bk] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    // the empty volatile statement "redefines" the accumulator inside this block: without it hipcc copies all 128 O registers
+                    // out of the accumulator file ABOVE the branch, on every tile
+                    asm volatile("" : "+a"(o[bk][dt]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[bk][dt][r] *= alpha;
+                }
+            }
+        }
+        // ---- gaps 8-55: P(j) spread over the score MFMAs of k steps 2-7 and the product MFMAs of key slabs 0-2; gaps 56-63: slab 3
+        float ps[2] = {0.f, 0.f};
+        const float negm[2] = {-m_run[0], -m_run[1]};
+        uint32_t pw[2][4][4];                                     // P(j): [block][key slab][word]
+        float t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;             // the two pairs in flight
+        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &negm, &t0, &t1, &u0, &u1, &frag, &dma_piece, kl, vl, t_dma, k_dma, v_dma, scale_log2e](auto gc) {
+            constexpr int g = decltype(gc)::value + 8;
+            constexpr bool is_qk = g < 32;
+            constexpr int q4 = g & 3, bk = q4 & 1, hf = q4 >> 1;                           // block, key half (scores) / d tile parity (product)
+            constexpr int ks = is_qk ? (g >> 2) : 0;                                        // score MFMA: k step
+            constexpr int st = is_qk ? 0 : ((g - 32) >> 2), sl = st >> 1, dt = 2 * (st & 1) + hf;   // product MFMA: step, key slab, d tile
+            constexpr int step = g >> 2, cur = step & 1;                                    // 16 steps of 4 MFMAs share 2 fragments
+            if constexpr (q4 == 0 && g < 60) {                                              // next step's fragments
+                constexpr int ns = step + 1;
+                if constexpr (ns < 8) { fa[cur ^ 1][0] = frag(kl, ns, 0); fa[cur ^ 1][1] = frag(kl, ns, 8192); }
+                else { constexpr int s2 = ns - 8; fa[cur ^ 1][0] = frag(vl, s2 >> 1, (2 * (s2 & 1)) * 4096); fa[cur ^ 1][1] = frag(vl, s2 >> 1, (2 * (s2 & 1) + 1) * 4096); }
+            }
+#ifndef F64_NO_DMA
+            if constexpr (g >= 10 && g <= 52 && (g - 10) % 6 == 0) dma_piece(t_dma, k_dma, v_dma, (g - 10) / 6);
+#endif
+            if constexpr (g >= 56) {
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
+                asm volatile("v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]" : [d] "+a"(o[bk][dt]) : [a] "v"(fa[cur][hf]), [b] "v"(pf));
+            } else {
+                // the exp stream: gaps 8-55 in triples, two pairs per triple; pair order: key slab, block, word
+                constexpr int tr = (g - 8) / 3, ph = (g - 8) % 3;
+                constexpr int qx = 2 * tr, qy = 2 * tr + 1;                                 // pairs 0..31
+                constexpr int xb = (qx >> 2) & 1, xsl = qx >> 3, xe = qx & 3, yb = (qy >> 2) & 1, ysl = qy >> 3, ye = qy & 3;
+                // scores of pair (block b, slab s, word e): S[b][s >> 1][8 (s & 1) + 2 e], + 1
+                const float xs0 = sc[xb][xsl >> 1][8 * (xsl & 1) + 2 * xe], xs1 = sc[xb][xsl >> 1][8 * (xsl & 1) + 2 * xe + 1];
+                const float ys0 = sc[yb][ysl >> 1][8 * (ysl & 1) + 2 * ye], ys1 = sc[yb][ysl >> 1][8 * (ysl & 1) + 2 * ye + 1];
+                if constexpr (is_qk) {
+                    if constexpr (ph == 0)
+                        asm volatile(F64_MFMA_S F64_EXP_A : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [nm] "v"(negm[xb]));
+                    else if constexpr (ph == 1)
+                        asm volatile(F64_MFMA_S F64_EXP_B : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [u0] "=&v"(u0), [u1] "=&v"(u1)
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [nm] "v"(negm[yb]));
+                    else
+                        asm volatile(F64_MFMA_S F64_EXP_C : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [u0] "v"(u0));
+                } else {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
+                    if constexpr (ph == 0)
+                        asm volatile(F64_MFMA_S F64_EXP_A : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [nm] "v"(negm[xb]));
+                    else if constexpr (ph == 1)
+                        asm volatile(F64_MFMA_S F64_EXP_B : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [u0] "=&v"(u0), [u1] "=&v"(u1)
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [nm] "v"(negm[yb]));
+                    else
+                        asm volatile(F64_MFMA_S F64_EXP_C : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [u0] "v"(u0));
+                }
+            }
+        });
+        l_run[0] += ps[0];
+        l_run[1] += ps[1];
+        adv(k_cur, K_RING); adv(k_dma, K_RING); adv(v_cur, V_RING); adv(v_dma, V_RING);
+    };
+    // tiles in pairs (the two S sets swap roles); the extra tile of an odd count is fully masked (P = 0)
+    for (int j = 0; j < n_tiles; j += 2) {
+        tile_body(j, sA, sB);
+        tile_body(j + 1, sB, sA);
+    }
+
+    // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3
+#pragma unroll
+    for (int bk = 0; bk < 2; ++bk) {
+        const float l_tot = l_run[bk] + __shfl_xor(l_run[bk], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qrow = qb.q0 + w * 64 + bk * 32 + l31;
+        if (qrow < n) {
+            bf16_t* op = O + ((size_t)(qb.tok0 + qrow) * Hq + h) * 128;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    u32x2 pk = {pack_bf2(o[bk][dt][4 * rq] * inv, o[bk][dt][4 * rq + 1] * inv),
+                                pack_bf2(o[bk][dt][4 * rq + 2] * inv, o[bk][dt][4 * rq + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * rq + 4 * hi) = pk;
+                }
+        }
+    }
+}
+#undef F64_QK_OPS
+#undef F64_PV_OPS
+
 }  // namespace
 
 hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
@@ -335,8 +604,9 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
     if (Hq % Hkv != 0) return hipErrorInvalidValue;
     const float c = scale * 1.44269504088896340736f;
     dim3 grid(n_blocks);                      // n_blocks = work items (seq x head x query block)
-    // DOTS_OCR_ATTN_MODE: 1 (default) = ping-pong halves + LDS fragment look-ahead, 0 = the round-1 schedule
-    static const int mode = getenv("DOTS_OCR_ATTN_MODE") ? atoi(getenv("DOTS_OCR_ATTN_MODE")) : 1;
+    // DOTS_OCR_ATTN_MODE: 2 (default) = bidirectional: 4 waves x 64 rows, LDS-DMA tiles, softmax interleaved with the MFMAs (round 4);
+    // causal: as 1.  1 = 8 waves, ping-pong halves + LDS fragment look-ahead (rounds 1-3), 0 = the round-1 schedule
+    static const int mode = getenv("DOTS_OCR_ATTN_MODE") ? atoi(getenv("DOTS_OCR_ATTN_MODE")) : 2;
     auto go = [&](auto kern, int threads, int lds) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -346,7 +616,16 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
         return hipGetLastError();
     };
     if (flash_rows_per_block() == 256) {
-        if (mode == 1) return causal ? go(flash_attn_kernel<true, 8, 1>, 512, 3 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 1>, 512, 3 * BUF_BYTES);
+        if (mode == 2 && !causal) {
+            static bool attr_done = false;            // one device per process image in practice; the attribute call is idempotent
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+            return hipGetLastError();
+        }
+        if (mode >= 1) return causal ? go(flash_attn_kernel<true, 8, 1>, 512, 3 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 1>, 512, 3 * BUF_BYTES);
         return causal ? go(flash_attn_kernel<true, 8, 0>, 512, 2 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 0>, 512, 2 * BUF_BYTES);
     }
     return causal ? go(flash_attn_kernel<true, 4, 0>, 256, 2 * BUF_BYTES) : go(flash_attn_kernel<false, 4, 0>, 256, 2 * BUF_BYTES);

@@ -107,23 +107,36 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split-KV decode attention.  grid (n_splits, Hkv, B), 4 waves; wave w walks pages split*4 + w,
-// += 4*n_splits.  All `group` (<= 16) query heads of one kv head share every K/V load (GQA).
+// Split-KV decode attention.  grid (n_splits, Hkv, B), NW waves; wave w walks pages split*NW + w,
+// += NW*n_splits.  All `group` (<= 16) query heads of one kv head share every K/V load (GQA).
 // Output per (b, hkv, split): unnormalised O [group][128] fp32, (m, l) [group].
 // n_splits is an engine constant (from max_seq_len), so which pages a split sums — and with it every bit of the
 // result — depends on the sequence's own context only, not on what else is in the batch or on the schedule.
 // Splits past the context's last page exit at once and are not read by the combine kernel.
-// Memory round trips: {context length, first page id, q} in one, then the page itself (32 KiB per wave in flight).
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
+// Memory round trips: {context length, first page id, q} in one, then the page itself.
+// Round 4 (register diet + conflict-free tail; same arithmetic, bit-identical results):
+//  * ONE = every wave owns at most one page (n_splits * NW >= max_pages: every context up to 16 k tokens).  O is then not
+//    loop-carried, K (16 chunks) and the first V slab (8 chunks) are requested together, the second V slab is requested into the
+//    registers K frees once S^T is computed: 24 KiB in flight per wave instead of 32, ~125 instead of 200 registers, so THREE
+//    workgroups per CU instead of two — on the 128-CU decode partition of the pipelined step all 368 working workgroups of the
+//    bench's batch are resident at once (two dispatch rounds before: 16.8 us per launch vs 11.7 on the whole chip).
+//  * the cross-wave combine buffer holds only the `group` live q columns, rows padded to AT_LD floats: one conflict-free
+//    ds_write_b128 per (lane, d group) instead of 32 ds_write_b32 that were 16-way bank conflicts (the in-kernel trace showed
+//    1.9 us between "pages done" and the barrier behind these writes).
+constexpr int AT_LD = 132;
+
+template <int NW, bool ONE>
+__global__ __launch_bounds__(NW * 64, ONE ? 3 : 2) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
                                                           const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
                                                           int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
                                                           int Hq, int Hkv, int n_splits, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) float lds_o[NW][16 * 128];
-    __shared__ float lds_m[NW][16], lds_l[NW][16];
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
     const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
     const int group = Hq / Hkv;
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, i = l & 15, g = l >> 4;
+    float* lds_o = reinterpret_cast<float*>(at_smem);                    // [NW][group][AT_LD]
+    float* lds_m = lds_o + NW * group * AT_LD;                           // [NW][16]
+    float* lds_l = lds_m + NW * 16;                                      // [NW][16]
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = l & 15, g = l >> 4;
     const int p0 = split * NW + w;
     TRACE(0);
     const int ctx = ctx_len[b] + 1;                       // includes the token appended this step
@@ -136,26 +149,29 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const bf16_t* __re
     const int n_pages = (ctx + PAGE - 1) / PAGE;
     if (split * NW >= n_pages) return;
     TRACE(1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const u32x4 z = {0, 0, 0, 0};
-        qf[kk] = __builtin_bit_cast(bf16x8, i < group ? qraw[kk] : z);
-    }
     f32x4 o[8];
 #pragma unroll
     for (int dg = 0; dg < 8; ++dg) o[dg] = f32x4{0, 0, 0, 0};
     float m_run = -1e30f, l_run = 0.f;
 
-    for (int p = p0; p < n_pages; p += NW * n_splits) {
-        if (p != p0) page = block_table[b * max_pages + p];
-        const bf16_t* kp = pool + ((size_t)(page * Hkv + hkv) * 2) * PAGE_ELEMS;
+    // one page: S^T = K.Q^T -> online softmax -> O^T += V^T.P^T.  The load / MFMA order is pinned (sched_barrier): K and V slab 0
+    // first, V slab 1 only once the K registers are free.
+    auto page_step = [&](int p, int pg, bool first) {
+        const bf16_t* kp = pool + ((size_t)(pg * Hkv + hkv) * 2) * PAGE_ELEMS;
         const bf16_t* vp = kp + PAGE_ELEMS;
-        bf16x8 kf[16], vf[16];
+        bf16x8 kf[16], va[8], vb[8];
 #pragma unroll
         for (int c = 0; c < 16; ++c) kf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kp + (size_t)(c * 64 + l) * 8));
+        __builtin_amdgcn_sched_barrier(0);                   // K before V: S^T waits for K only (a wave's loads return in order)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) vf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vp + (size_t)(c * 64 + l) * 8));
+        for (int c = 0; c < 8; ++c) va[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vp + (size_t)(c * 64 + l) * 8));
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x4 z = {0, 0, 0, 0};
+            qf[kk] = __builtin_bit_cast(bf16x8, i < group ? qraw[kk] : z);
+        }
         // S^T[kg] : rows = keys 16kg + 4g + r, col = q head i
         f32x4 s[4];
 #pragma unroll
@@ -164,6 +180,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const bf16_t* __re
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) s[kg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kg * 4 + kk], qf[kk], s[kg], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vb[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vp + (size_t)((c + 8) * 64 + l) * 8));
+        __builtin_amdgcn_sched_barrier(0);
         const int key0 = p * PAGE;
         float mx = -INFINITY;
 #pragma unroll
@@ -198,40 +218,49 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const bf16_t* __re
             pf[slab] = __builtin_bit_cast(bf16x8, pk);
         }
         l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dg = 0; dg < 8; ++dg)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dg][r] *= alpha;
-        // V chunks arrive in order (slab 0: dg 0..7, then slab 1): consume them in that order
-#pragma unroll
-        for (int slab = 0; slab < 2; ++slab)
+        if (!first) {            // O is still zero before a wave's first page: nothing to rescale (0 * alpha = 0 exactly)
 #pragma unroll
             for (int dg = 0; dg < 8; ++dg)
-                o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[slab * 8 + dg], pf[slab], o[dg], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dg][r] *= alpha;
+        }
+        // V chunks arrive in order (slab 0: dg 0..7, then slab 1): consume them in that order
+#pragma unroll
+        for (int dg = 0; dg < 8; ++dg) o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dg], pf[0], o[dg], 0, 0, 0);
+#pragma unroll
+        for (int dg = 0; dg < 8; ++dg) o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[dg], pf[1], o[dg], 0, 0, 0);
+    };
+    if constexpr (ONE) {
+        if (p0 < n_pages) page_step(p0, page, true);
+    } else {
+        for (int p = p0; p < n_pages; p += NW * n_splits) {
+            if (p != p0) page = block_table[b * max_pages + p];
+            page_step(p, page, p == p0);
+        }
     }
     TRACE(2);
     // wave partial: l over the 4 lane groups that share a q column
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    if (g == 0) { lds_m[w][i] = m_run; lds_l[w][i] = l_run; }
+    if (g == 0) { lds_m[w * 16 + i] = m_run; lds_l[w * 16 + i] = l_run; }
+    if (i < group) {
 #pragma unroll
-    for (int dg = 0; dg < 8; ++dg)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_o[w][i * 128 + dg * 16 + 4 * g + r] = o[dg][r];     // O^T[d = 16dg+4g+r][q = i]
+        for (int dg = 0; dg < 8; ++dg) *reinterpret_cast<f32x4*>(lds_o + (w * group + i) * AT_LD + dg * 16 + 4 * g) = o[dg];     // O^T[d = 16dg+4g+r][q = i]
+    }
     __syncthreads();
     TRACE(3);
     // combine the NW waves: thread -> (q head j, d) pairs
     for (int item = threadIdx.x; item < group * 128; item += NW * 64) {
         const int j = item >> 7, d = item & 127;
-        float m = lds_m[0][j];
+        float m = lds_m[j];
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) m = fmaxf(m, lds_m[ww][j]);
+        for (int ww = 1; ww < NW; ++ww) m = fmaxf(m, lds_m[ww * 16 + j]);
         float acc = 0.f, lsum = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
-            const float f = __builtin_amdgcn_exp2f(lds_m[ww][j] - m);
-            acc += lds_o[ww][j * 128 + d] * f;
-            lsum += lds_l[ww][j] * f;
+            const float f = __builtin_amdgcn_exp2f(lds_m[ww * 16 + j] - m);
+            acc += lds_o[(ww * group + j) * AT_LD + d] * f;
+            lsum += lds_l[ww * 16 + j] * f;
         }
         const size_t base = (((size_t)b * Hkv + hkv) * n_splits + split) * group + j;
         part_o[base * 128 + d] = acc;
@@ -491,11 +520,16 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
     if (Hq % Hkv != 0 || Hq / Hkv > 16) return hipErrorInvalidValue;
     const float sl = scale * 1.44269504088896340736f;
     const dim3 grid(n_splits, Hkv, B);
-    switch (decode_attn_waves()) {
-        case 1: hipLaunchKernelGGL(decode_attn_kernel<1>, grid, dim3(64), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
-        case 2: hipLaunchKernelGGL(decode_attn_kernel<2>, grid, dim3(128), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
-        default: hipLaunchKernelGGL(decode_attn_kernel<4>, grid, dim3(256), 0, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl); break;
+    const int nw = decode_attn_waves(), group = Hq / Hkv;
+    const size_t lds = ((size_t)nw * group * AT_LD + 2 * nw * 16) * sizeof(float);
+    const bool one = (int64_t)n_splits * nw >= max_pages;        // every wave owns at most one page: the light-weight instantiation
+#define ATTN_GO(NWV, ONEV) hipLaunchKernelGGL((decode_attn_kernel<NWV, ONEV>), grid, dim3(NWV * 64), lds, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl)
+    switch (nw) {
+        case 1: if (one) ATTN_GO(1, true); else ATTN_GO(1, false); break;
+        case 2: if (one) ATTN_GO(2, true); else ATTN_GO(2, false); break;
+        default: if (one) ATTN_GO(4, true); else ATTN_GO(4, false); break;
     }
+#undef ATTN_GO
     return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@
 // u32x2 (8 e4m3 bytes) — which is converted to the bf16 MFMA operand in registers (4 v_cvt_scalef32_pk_bf16_fp8, exact) when
 // its MFMA issues; the per-output-channel scale is one more small operand of step 1 and multiplies the reduced accumulator in
 // the epilogue.  Half the bytes per step, the same arithmetic as the bf16(q) x scale GEMMs of prefill.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -319,6 +320,12 @@ constexpr int GU_EARLY = GU_EARLY_N;      // k-steps requested before the norm p
 
 // PAIRS (gate tile, up tile) pairs per workgroup: waves [p * GU_WAVES, (p + 1) * GU_WAVES) split the K of pair p; all PAIRS * GU_WAVES
 // waves share one norm prologue, so the residual rows are fetched and normalised by half as many workgroups when PAIRS = 2.
+// Round 4: the workgroup WALKS the pair groups blockIdx.y, blockIdx.y + gridDim.y, ... (one norm prologue, the X image stays in LDS).  With
+// gridDim.y = I / 16 / PAIRS (the whole-chip plan) that is exactly one group per workgroup, as before; on a stream that is CU-masked
+// to the decode partition of the pipelined step the launcher caps the grid at what the partition holds at once (4 workgroups per CU),
+// so the 560 pairs of dots.ocr run as ONE resident round whose leftover pairs are picked up by workgroups that are already there
+// (norm done, streaming) instead of a second dispatch round of cold workgroups.  A group's next weights are requested right after its
+// MFMAs, before the split-K reduction and the SwiGLU epilogue.  Same arithmetic per element.
 template <int MAXR, int NC, typename WT, int PAIRS>
 __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                                    const WT* __restrict__ Wd, const float* __restrict__ wscale, bf16_t* __restrict__ act,
@@ -332,29 +339,34 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [PAIRS * GU_WAVES][2][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int pw = wv / GU_WAVES, kw = wv % GU_WAVES;                             // pair inside the workgroup, K slice
-    const int pair = blockIdx.y * PAIRS + pw, G = pair >> 1, a = pair & 1;
+    const int n_pairs = I / 16;
+    int pair = blockIdx.y * PAIRS + pw;                                           // < n_pairs (launcher: gridDim.y * PAIRS <= n_pairs)
     const int KS = H / 32;
     const int k0 = kw * KS / GU_WAVES, k1 = (kw + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
     const int xstride = 4 * XR;
     const int ls = lane_slot<WT>(lane >> 4, lane & 15);
-    const WT* wg = Wd + ((size_t)(G * 4 + a) * KS) * 64 + ls;
-    const WT* wu = Wd + ((size_t)(G * 4 + 2 + a) * KS) * 64 + ls;
+    const int m = lane & 15, g = lane >> 4;
+    // wave-uniform chunk bases (scalar registers); the lane's slot `ls` is added per load
+    auto gate_ptr = [&](int pr) { return Wd + ((size_t)((pr >> 1) * 4 + (pr & 1)) * KS + k0) * 64; };
+    auto up_ptr = [&](int pr) { return Wd + ((size_t)((pr >> 1) * 4 + 2 + (pr & 1)) * KS + k0) * 64; };
+    const WT* wg = gate_ptr(pair);
+    const WT* wu = up_ptr(pair);
     TRACE(0);
     Rows<MAXR, NC> R;
     rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, PAIRS * GU_WAVES, lane);
-    f32x4 scg = {1.f, 1.f, 1.f, 1.f}, scu = {1.f, 1.f, 1.f, 1.f};       // packed-W13 rows (G*4 + a)*16 + 4g + r (gate), + 32 (up)
-    if constexpr (is_fp8<WT>::value) {
-        scg = *reinterpret_cast<const f32x4*>(wscale + (G * 4 + a) * 16 + 4 * (lane >> 4));
-        scu = *reinterpret_cast<const f32x4*>(wscale + (G * 4 + 2 + a) * 16 + 4 * (lane >> 4));
-    }
+    // fp8: per-output-channel scales of the packed-W13 rows (G*4 + a)*16 + 4g + r (gate), + 32 (up): small operands, fetched with the rows
+    auto scale_g = [&](int pr) { return *reinterpret_cast<const f32x4*>(wscale + ((pr >> 1) * 4 + (pr & 1)) * 16 + 4 * g); };
+    auto scale_u = [&](int pr) { return *reinterpret_cast<const f32x4*>(wscale + ((pr >> 1) * 4 + 2 + (pr & 1)) * 16 + 4 * g); };
+    f32x4 scg = {1.f, 1.f, 1.f, 1.f}, scu = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) { scg = scale_g(pair); scu = scale_u(pair); }
     __builtin_amdgcn_sched_barrier(0);
     WT a_[GU_G], u_[GU_G];
-    const WT* zc = reinterpret_cast<const WT*>(g_zero_chunk) + lane;
+    const WT* zc = reinterpret_cast<const WT*>(g_zero_chunk);          // a slice shorter than GU_G reads zeros: uniform pointer select, no branch
 #pragma unroll
     for (int jj = 0; jj < GU_EARLY; ++jj) {
-        a_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wg + (size_t)(k0 + jj) * 64 : zc);
-        u_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wu + (size_t)(k0 + jj) * 64 : zc);
+        a_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wg + (size_t)jj * 64 : zc) + ls);
+        u_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wu + (size_t)jj * 64 : zc) + ls);
     }
     __builtin_amdgcn_sched_barrier(0);
     pin_rows<MAXR, NC>(R);
@@ -364,36 +376,57 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = GU_EARLY; jj < GU_G; ++jj) {
-        a_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wg + (size_t)(k0 + jj) * 64 : zc);
-        u_[jj] = __builtin_nontemporal_load(k0 + jj < k1 ? wu + (size_t)(k0 + jj) * 64 : zc);
+        a_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wg + (size_t)jj * 64 : zc) + ls);
+        u_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wu + (size_t)jj * 64 : zc) + ls);
     }
     __builtin_amdgcn_sched_barrier(0);
     TRACE(2);
-    __syncthreads();
-    TRACE(3);
-    f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
+    for (;;) {
+        __syncthreads();                                   // the X image is complete / the reduction buffer of the previous group has been read
+        TRACE(3);
+        f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
 #pragma unroll
-    for (int jj = 0; jj < GU_G; ++jj) {
-        const bf16x8 b = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
-        ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a_[jj]), b, ag, 0, 0, 0);
-        au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(u_[jj]), b, au, 0, 0, 0);
+        for (int jj = 0; jj < GU_G; ++jj) {
+            const bf16x8 b = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a_[jj]), b, ag, 0, 0, 0);
+            au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(u_[jj]), b, au, 0, 0, 0);
+        }
+        TRACE(4);
+        const int cur = pair;
+        pair += gridDim.y * PAIRS;
+        const bool more = pair < n_pairs;                  // uniform over the workgroup (PAIRS divides n_pairs: launcher)
+        f32x4 scg_n = scg, scu_n = scu;
+        if (more) {                                        // the next group's weights: requested before this group's reduction and epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (is_fp8<WT>::value) { scg_n = scale_g(pair); scu_n = scale_u(pair); }
+            wg = gate_ptr(pair);
+            wu = up_ptr(pair);
+#pragma unroll
+            for (int jj = 0; jj < GU_G; ++jj) {
+                a_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wg + (size_t)jj * 64 : zc) + ls);
+                u_[jj] = __builtin_nontemporal_load((k0 + jj < k1 ? wu + (size_t)jj * 64 : zc) + ls);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        red[(wv * 2) * 64 + lane] = ag;
+        red[(wv * 2 + 1) * 64 + lane] = au;
+        __syncthreads();
+        TRACE(5);
+        if (kw == 0 && m < B) {
+            const int G = cur >> 1, a = cur & 1;
+            f32x4 gs = ag, us = au;
+#pragma unroll
+            for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[((pw * GU_WAVES + ww) * 2) * 64 + lane]; us += red[((pw * GU_WAVES + ww) * 2 + 1) * 64 + lane]; }
+            if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
+            store_frag4(act, m, G * 32 + a * 16 + 4 * g, XR, o[0], o[1], o[2], o[3]);
+        }
+        TRACE(6);
+        if (!more) break;
+        scg = scg_n; scu = scu_n;
     }
-    TRACE(4);
-    red[(wv * 2) * 64 + lane] = ag;
-    red[(wv * 2 + 1) * 64 + lane] = au;
-    __syncthreads();
-    TRACE(5);
-    const int m = lane & 15, g = lane >> 4;
-    if (kw != 0 || m >= B) return;
-    f32x4 gs = ag, us = au;
-#pragma unroll
-    for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[((pw * GU_WAVES + ww) * 2) * 64 + lane]; us += red[((pw * GU_WAVES + ww) * 2 + 1) * 64 + lane]; }
-    if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
-    float o[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
-    store_frag4(act, m, G * 32 + a * 16 + 4 * g, XR, o[0], o[1], o[2], o[3]);
-    TRACE(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,39 +574,61 @@ hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const
     return hipGetLastError();
 }
 
+// part_cus > 0: the stream is CU-masked to that many CUs (the decode partition of the pipelined step): the grid is capped at what those CUs
+// hold at once (occupancy query, cached per kernel) and the kernel walks the remaining pair groups.
+template <typename Kern>
+static int resident_blocks_per_cu(Kern kern, int threads, size_t lds, int* cache) {
+    int v = __atomic_load_n(cache, __ATOMIC_ACQUIRE);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), threads, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    __atomic_store_n(cache, n, __ATOMIC_RELEASE);
+    return n;
+}
+
 template <typename WT>
 static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const WT* W13d, const float* wscale, bf16_t* act,
-                                int B, int H, int I, float eps) {
+                                int B, int H, int I, float eps, int part_cus) {
     static uint32_t attr[2] = {0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const int v = B <= 8 ? 0 : 1;
+    static const int cap_env = [] { const char* e = getenv("DOTS_OCR_GATEUP_WG_CAP"); return e ? atoi(e) : 0; }();     // tests / A-B runs: force the walking path
+    const int tiles = (B + 15) / 16;
     // 2 pairs per workgroup (8 waves, two rows per wave) for the 16-row image: 14.7 vs 16.4 us at B = 16 (four rows per wave otherwise);
     // at B <= 8 one pair per workgroup is faster (13.3 vs 13.9 us at B = 8, 11.9 vs 13.6 at B = 1).  DOTS_OCR_GATEUP_PAIRS=1/2 forces either.
     static const int pairs_env = [] { const char* e = getenv("DOTS_OCR_GATEUP_PAIRS"); return e ? atoi(e) : 0; }();
     const int pairs = pairs_env ? pairs_env : (B > 8 ? 2 : 1);
     if (pairs == 2 && (I / 16) % 2 == 0) {
         static uint32_t attr2[2] = {0, 0};
+        static int occ2[2] = {0, 0};
         const size_t lds2 = (size_t)XR * H * 2 + 4 * GU_WAVES * 64 * sizeof(f32x4), lds2_max = (size_t)16 * H * 2 + 4 * GU_WAVES * 64 * sizeof(f32x4);
         auto kern2 = v == 0 ? dec_gateup_kernel<1, NC_MAX, WT, 2> : dec_gateup_kernel<2, NC_MAX, WT, 2>;
         hipError_t e2 = ensure_lds(kern2, lds2_max, &attr2[v]);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(kern2, dim3((B + 15) / 16, I / 32), dim3(2 * GU_WAVES * 64), lds2, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+        int gy = I / 32;
+        const int cap = cap_env > 0 ? cap_env : (part_cus > 0 ? part_cus * resident_blocks_per_cu(kern2, 2 * GU_WAVES * 64, lds2, &occ2[v]) : 0);
+        if (cap > 0) gy = std::max(1, std::min(gy, cap / tiles));
+        hipLaunchKernelGGL(kern2, dim3(tiles, gy), dim3(2 * GU_WAVES * 64), lds2, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
         return hipGetLastError();
     }
+    static int occ1[2] = {0, 0};
     const size_t lds = (size_t)XR * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
     const size_t lds_max = (size_t)16 * H * 2 + 2 * GU_WAVES * 64 * sizeof(f32x4);
     auto kern = v == 0 ? dec_gateup_kernel<2, NC_MAX, WT, 1> : dec_gateup_kernel<4, NC_MAX, WT, 1>;
     hipError_t e = ensure_lds(kern, lds_max, &attr[v]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((B + 15) / 16, I / 16), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
+    int gy = I / 16;
+    const int cap = cap_env > 0 ? cap_env : (part_cus > 0 ? part_cus * resident_blocks_per_cu(kern, GU_WAVES * 64, lds, &occ1[v]) : 0);
+    if (cap > 0) gy = std::max(1, std::min(gy, cap / tiles));
+    hipLaunchKernelGGL(kern, dim3(tiles, gy), dim3(GU_WAVES * 64), lds, s, h, ln_w, W13d, wscale, act, B, H, I, eps, XR);
     return hipGetLastError();
 }
 
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
-                             int B, int H, int I, float eps) {
+                             int B, int H, int I, float eps, int part_cus) {
     if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
-    return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps)
-                  : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps);
+    return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps, part_cus)
+                  : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps, part_cus);
 }
 
 template <typename WT>

@@ -1007,7 +1007,7 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
     const float scale = 1.0f / sqrtf(128.0f);
     CK(launch_dec_embed(s, e->cur_tokens, e->embed, e->d_h, B, H));
     const bool flow = e->flow_mode == 1 && flow_supported(B, H, Hq, Hkv, I);
-    if (e->flow_mode == 2 && B <= 8) part = 1;                                     // dots_set_decode_flow(2): the half-chip plan on every step (tests, A/B runs)
+    if (e->flow_mode == 2) part = 1;                                               // dots_set_decode_flow(2): the partition plan on every step (tests, A/B runs)
     if (flow) CK(hipMemsetAsync(e->flow_sync, 0, e->flow_sync_bytes, s));         // a memset node at the head of every replay
     static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
     for (int i = 0; i < c.num_layers; ++i) {
@@ -1030,7 +1030,7 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
         CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part));
-        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps));
+        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0));
         CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part));
     }
     CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
@@ -1333,7 +1333,7 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     hipGraphExec_t exec_part = nullptr;            // the step captured with the half-chip launch plan, for the masked stream
     if (use_graph && max_new_tokens > 1) {
         if (e->step_graphs.size() >= 30) drop_step_graphs(e);          // so that neither lookup below can evict the other's graph
-        if (e->s_vit && B <= 8 && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
+        if (e->s_vit && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
         RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
     }
     std::vector<int32_t> fin(DOTS_MAX_BATCH);
@@ -1470,7 +1470,7 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     // half-chip launch plan when the rows allow it — exactly as dots_generate does
     hipStream_t cur = s;
     if (use_graph) { int r0 = pick_decode_stream(e, &cur); if (r0 != DOTS_OK) { e->B = 0; return r0; } }
-    const int part = (cur != s && rows <= 8 && e->flow_mode == 0) ? 1 : 0;
+    const int part = (cur != s && e->flow_mode == 0) ? 1 : 0;
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
         int r = step_graph(e, rows, n_splits, 0, &exec, part);

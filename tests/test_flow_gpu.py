@@ -86,6 +86,21 @@ def test_batch_of_nine_falls_back(tiny):
     ids, ln = _prompts(cfg, [20 + 3 * i for i in range(9)], seed=2)
     ref = _decode(eng, 0, ids, ln, 3)
     _assert_same(ref, _decode(eng, 1, ids, ln, 3), "B = 9 (launch-per-phase fallback)")
+    _assert_same(ref, _decode(eng, 2, ids, ln, 3), "B = 9, partition plan (16-row X image)")
+
+
+def test_partition_plan_above_16_rows_bitwise():
+    """Round 4: the partition plan (whole-tile projections, pair-walking gate|up) is no longer limited to 8 rows — continuous batching
+    with 9-64 occupied slots replays it beside a prefetched tower.  20 rows = two 16-row batch tiles."""
+    from dots_ocr_amd.engine import Engine
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=12)
+    eng = Engine(cfg, max_batch=20, max_seq_len=512, max_patches=256, max_prefill_tokens=4096)
+    eng.load_state_dict(sd)
+    ids, ln = _prompts(cfg, [17 + 11 * i for i in range(20)], seed=13)
+    ref = _decode(eng, 0, ids, ln, 4)
+    _assert_same(ref, _decode(eng, 2, ids, ln, 4), "B = 20, partition plan")
+    eng.close()
 
 
 def test_flow_walks_several_pages_per_wave_beyond_16k_context():
