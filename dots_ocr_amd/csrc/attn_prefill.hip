@@ -358,11 +358,27 @@ constexpr int RING_BYTES = (K_RING + V_RING) * KT_BYTES;      // KT_BYTES == VT_
 
 #define F64_MFMA_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], 0\n\t"
 #define F64_MFMA_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
-#define F64_MAX4 "v_max3_f32 %[mx], %[mx], %[x0], %[x1]\n\tv_max3_f32 %[mx], %[mx], %[x2], %[x3]\n\tv_max3_f32 %[mx], %[mx], %[x4], %[x5]\n\tv_max3_f32 %[mx], %[mx], %[x6], %[x7]"
-// exp stream of two pairs X, Y over three gaps (5 + 5 + 4 instructions)
-#define F64_EXP_A "v_fma_f32 %[t0], %[x0], %[sc], %[nm]\n\tv_fma_f32 %[t1], %[x1], %[sc], %[nm]\n\tv_exp_f32_e32 %[t0], %[t0]\n\tv_exp_f32_e32 %[t1], %[t1]\n\tv_add_f32_e32 %[ps], %[ps], %[t0]"
-#define F64_EXP_B "v_add_f32_e32 %[ps], %[ps], %[t1]\n\tv_cvt_pk_bf16_f32 %[wx], %[t0], %[t1]\n\tv_fma_f32 %[u0], %[y0], %[sc], %[nm]\n\tv_fma_f32 %[u1], %[y1], %[sc], %[nm]\n\tv_exp_f32_e32 %[u0], %[u0]"
+#define F64_MAX5 "v_max3_f32 %[mx], %[mx], %[x0], %[x1]\n\tv_max3_f32 %[mx], %[mx], %[x2], %[x3]\n\tv_max3_f32 %[mx], %[mx], %[x4], %[x5]\n\tv_max3_f32 %[mx], %[mx], %[x6], %[x7]\n\tv_max3_f32 %[mx], %[mx], %[x8], %[x9]"
+#define F64_MAX6 F64_MAX5 "\n\tv_max3_f32 %[mx], %[mx], %[xa], %[xb]"
+// decision chain, part 1 (gap 6): the two half-waves hold disjoint key subsets of the same rows -> exchange by v_permlane32_swap (a
+// ds_bpermute would park the wave for an LDS round trip); mx <- c = scaled row maximum of S(j).  The s_nop is the VALU-write -> permlane
+// read hazard.  Part 2 (gap 7): need = any row of the wave exceeds its running maximum by more than the threshold (wave-uniform mask);
+// m <- need ? max(m, c) : m, branch-free — O and l are rescaled later, in front of the first product MFMA, out of line.
+#define F64_CHAIN1 "v_mov_b32 %[t0], %[mx0]\n\tv_mov_b32 %[t1], %[mx1]\n\ts_nop 1\n\tv_permlane32_swap_b32 %[t0], %[mx0]\n\tv_permlane32_swap_b32 %[t1], %[mx1]\n\t" \
+                   "v_max_f32 %[mx0], %[t0], %[mx0]\n\tv_max_f32 %[mx1], %[t1], %[mx1]\n\tv_mul_f32 %[mx0], %[sc], %[mx0]\n\tv_mul_f32 %[mx1], %[sc], %[mx1]"
+#define F64_CHAIN2 "v_sub_f32 %[t0], %[mx0], %[m0]\n\tv_sub_f32 %[t1], %[mx1], %[m1]\n\tv_cmp_lt_f32 %[k0], %[thr], %[t0]\n\tv_cmp_lt_f32 %[k1], %[thr], %[t1]\n\t" \
+                   "v_max_f32 %[t0], %[m0], %[mx0]\n\tv_max_f32 %[t1], %[m1], %[mx1]\n\ts_or_b64 %[k0], %[k0], %[k1]\n\ts_cmp_lg_u64 %[k0], 0\n\ts_cselect_b64 %[k0], -1, 0\n\t" \
+                   "v_cndmask_b32 %[m0], %[m0], %[t0], %[k0]\n\tv_cndmask_b32 %[m1], %[m1], %[t1], %[k0]"
+// exp stream of two pairs X, Y over three gaps (5 + 5 + 4 instructions): p = exp2(s c - m) -> packed bf16x2 word of P, row sum
+#ifdef F64_NO_EXP
+#define F64_EXP_A ""
+#define F64_EXP_B ""
+#define F64_EXP_C ""
+#else
+#define F64_EXP_A "v_fma_f32 %[t0], %[x0], %[sc], -%[m]\n\tv_fma_f32 %[t1], %[x1], %[sc], -%[m]\n\tv_exp_f32_e32 %[t0], %[t0]\n\tv_exp_f32_e32 %[t1], %[t1]\n\tv_add_f32_e32 %[ps], %[ps], %[t0]"
+#define F64_EXP_B "v_add_f32_e32 %[ps], %[ps], %[t1]\n\tv_cvt_pk_bf16_f32 %[wx], %[t0], %[t1]\n\tv_fma_f32 %[u0], %[y0], %[sc], -%[m]\n\tv_fma_f32 %[u1], %[y1], %[sc], -%[m]\n\tv_exp_f32_e32 %[u0], %[u0]"
 #define F64_EXP_C "v_exp_f32_e32 %[u1], %[u1]\n\tv_add_f32_e32 %[ps], %[ps], %[u0]\n\tv_add_f32_e32 %[ps], %[ps], %[u1]\n\tv_cvt_pk_bf16_f32 %[wy], %[u0], %[u1]"
+#endif
 
 // compile-time loop: the gap index must be a constant expression (operand selection by `if constexpr`, never by run-time selects)
 template <int... I, class F> DEVI void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
@@ -425,7 +441,12 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
     const int k_lane = l31 * 256 + ((((l31 & 15) >> 1) << 5) | ((hi ^ (l31 & 1)) << 4));
     const int vsw = (l31 >> 1) & 7;
     const int v_lane = l31 * 128 + (((vsw >> 1) << 5) | ((hi ^ (vsw & 1)) << 4));
-    auto frag = [&](int base, int x, int imm) { return *reinterpret_cast<const bf16x8*>(smem + ((base ^ (x << 5)) + imm)); };
+    // (base includes the LDS address of the dynamic segment, a multiple of 16 KiB in this kernel — it has no static LDS — so the XOR with
+    // ks << 5 still only touches bits 5-7; addressing by integer avoids one "+ symbol" VALU add per fragment)
+    const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto frag = [&](int base, int x, int imm) {
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(uint32_t)((base ^ (x << 5)) + imm));
+    };
 
     // ring positions: K(j+1), V^T(j), and the stages tile j+3 goes to
     int k_cur = 1, v_cur = 0, k_dma = 0, v_dma = 3;
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 f0 = frag(k_lane, ks, 0), f1 = frag(k_lane, ks, 8192);
+        const bf16x8 f0 = frag(lds0 + k_lane, ks, 0), f1 = frag(lds0 + k_lane, ks, 8192);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             if (ks == 0) asm volatile(F64_MFMA_S0 : [d] "=&v"(sA[q4 & 1][q4 >> 1]) : [a] "v"(q4 >> 1 ? f1 : f0), [b] "a"(qf[q4 & 1][0]));
@@ -445,76 +466,106 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         }
     }
 
+#ifdef F64_PROF
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define F64_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define F64_STAMP(i)
+#endif
     // one tile: sc = S(j) (complete), sn <- S(j+1)
     auto tile_body = [&](int j, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
+#ifdef F64_PROF
+        unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
         // every wave's pieces of tile j+1 have landed (tile j+2's 8 may still fly) and every wave is done with the stages tile j+3 overwrites
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        F64_STAMP(0);                                             // wait + barrier
         const int t_dma = min(j + 3, t_last);
-        const int kl = k_lane + k_cur * KT_BYTES, vl = v_lane + (K_RING + v_cur) * KT_BYTES;
+        const int kl = lds0 + k_lane + k_cur * KT_BYTES, vl = lds0 + v_lane + (K_RING + v_cur) * KT_BYTES;
         bf16x8 fa[2][2];                                          // fragment pairs, one step ahead
         fa[0][0] = frag(kl, 0, 0);
         fa[0][1] = frag(kl, 0, 8192);
-        // ---- gaps 0-7: score MFMAs of k steps 0, 1 || row maxima of S(j)
+        const int key0 = j * 64;
+        if (key0 + 64 > n) {                                      // ragged last tile / the padding tile of an odd count (rare): keys past the end
+#pragma unroll                                                    // hold whatever the spare K rows held -> -inf before the maxima see them
+            for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+                for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        sc[bk][tq][r] = key < n ? sc[bk][tq][r] : -INFINITY;
+                    }
+        }
+        // ---- gaps 0-5: score MFMAs || row maxima of S(j) (6 + 5 + 5 v_max3 per block); gaps 6-7: the decision chain
         float mx[2] = {-INFINITY, -INFINITY};
-        static_for<8>([&sn, &sc, &mx, &qf, &fa, &frag, kl](auto gc) {   // explicit captures: clang does not capture a variable that is used by asm operands only
+        const float m_old[2] = {m_run[0], m_run[1]};
+        unsigned long long need = 0;
+        static_for<8>([&sn, &sc, &mx, &qf, &fa, &frag, &m_run, &need, kl, scale_log2e](auto gc) {   // explicit captures: clang does not capture a variable that is used by asm operands only
             constexpr int g = decltype(gc)::value;
             constexpr int ks = g >> 2, q4 = g & 3, bk = q4 & 1, tt = q4 >> 1, cur = ks & 1;
             if constexpr (q4 == 0) { fa[cur ^ 1][0] = frag(kl, ks + 1, 0); fa[cur ^ 1][1] = frag(kl, ks + 1, 8192); }
-            constexpr int mb = g >> 2, mt = (g >> 1) & 1, r0 = 8 * (g & 1);          // 8 scores of block mb
-            const f32x16& xs = sc[mb][mt];
-            if constexpr (ks == 0)
-                asm volatile(F64_MFMA_S0 F64_MAX4 : [d] "=&v"(sn[bk][tt]), [mx] "+v"(mx[mb])
-                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][0]), [x0] "v"(xs[r0]), [x1] "v"(xs[r0 + 1]), [x2] "v"(xs[r0 + 2]), [x3] "v"(xs[r0 + 3]),
-                               [x4] "v"(xs[r0 + 4]), [x5] "v"(xs[r0 + 5]), [x6] "v"(xs[r0 + 6]), [x7] "v"(xs[r0 + 7]));
-            else
-                asm volatile(F64_MFMA_S F64_MAX4 : [d] "+v"(sn[bk][tt]), [mx] "+v"(mx[mb])
-                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [x0] "v"(xs[r0]), [x1] "v"(xs[r0 + 1]), [x2] "v"(xs[r0 + 2]), [x3] "v"(xs[r0 + 3]),
-                               [x4] "v"(xs[r0 + 4]), [x5] "v"(xs[r0 + 5]), [x6] "v"(xs[r0 + 6]), [x7] "v"(xs[r0 + 7]));
-        });
-        // ---- the product of tile j-1 is complete: mask of a ragged tile, rescale — both rare
-        const int key0 = j * 64;
-        if (key0 + 64 > n) {
-#pragma unroll
-            for (int bk = 0; bk < 2; ++bk) {
-                float mm = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        sc[bk][t][r] = key < n ? sc[bk][t][r] : -INFINITY;
-                        mm = fmaxf(mm, sc[bk][t][r]);
-                    }
-                mx[bk] = mm;                                      // rows past the end hold whatever the spare K rows held: out of the maximum
-            }
-        }
-        const float c0 = fmaxf(mx[0], __shfl_xor(mx[0], 32, 64)) * scale_log2e, c1 = fmaxf(mx[1], __shfl_xor(mx[1], 32, 64)) * scale_log2e;
-        if (!__all(c0 - m_run[0] <= RESCALE_THR && c1 - m_run[1] <= RESCALE_THR)) {
-            const float cc[2] = {c0, c1};
-#pragma unroll
-            for (int bk = 0; bk < 2; ++bk) {
-                const float m_new = fmaxf(m_run[bk], cc[bk]);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[bk] - m_new);
-                m_run[bk] = m_new;
-                l_run[bk] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    // the empty volatile statement "redefines" the accumulator inside this block: without it hipcc copies all 128 O registers
-                    // out of the accumulator file ABOVE the branch, on every tile
-                    asm volatile("" : "+a"(o[bk][dt]));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[bk][dt][r] *= alpha;
+            if constexpr (g < 6) {
+                constexpr int mb = g / 3, v0 = (g % 3 == 0) ? 0 : (g % 3 == 1 ? 12 : 22);       // scores v0 .. of block mb, flattened [t][r]
+                const f32x16 (&xs)[2] = sc[mb];
+#define XV(i) xs[(v0 + (i)) >> 4][(v0 + (i)) & 15]
+                if constexpr (g % 3 == 0) {
+                    if constexpr (ks == 0)
+                        asm volatile(F64_MFMA_S0 F64_MAX6 : [d] "=&v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                                     : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][0]), [x0] "v"(XV(0)), [x1] "v"(XV(1)), [x2] "v"(XV(2)), [x3] "v"(XV(3)), [x4] "v"(XV(4)), [x5] "v"(XV(5)),
+                                       [x6] "v"(XV(6)), [x7] "v"(XV(7)), [x8] "v"(XV(8)), [x9] "v"(XV(9)), [xa] "v"(XV(10)), [xb] "v"(XV(11)));
+                    else
+                        asm volatile(F64_MFMA_S F64_MAX6 : [d] "+v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                                     : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [x0] "v"(XV(0)), [x1] "v"(XV(1)), [x2] "v"(XV(2)), [x3] "v"(XV(3)), [x4] "v"(XV(4)), [x5] "v"(XV(5)),
+                                       [x6] "v"(XV(6)), [x7] "v"(XV(7)), [x8] "v"(XV(8)), [x9] "v"(XV(9)), [xa] "v"(XV(10)), [xb] "v"(XV(11)));
+                } else {
+                    if constexpr (ks == 0)
+                        asm volatile(F64_MFMA_S0 F64_MAX5 : [d] "=&v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                                     : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][0]), [x0] "v"(XV(0)), [x1] "v"(XV(1)), [x2] "v"(XV(2)), [x3] "v"(XV(3)), [x4] "v"(XV(4)), [x5] "v"(XV(5)),
+                                       [x6] "v"(XV(6)), [x7] "v"(XV(7)), [x8] "v"(XV(8)), [x9] "v"(XV(9)));
+                    else
+                        asm volatile(F64_MFMA_S F64_MAX5 : [d] "+v"(sn[bk][tt]), [mx] "+v"(mx[mb])
+                                     : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [x0] "v"(XV(0)), [x1] "v"(XV(1)), [x2] "v"(XV(2)), [x3] "v"(XV(3)), [x4] "v"(XV(4)), [x5] "v"(XV(5)),
+                                       [x6] "v"(XV(6)), [x7] "v"(XV(7)), [x8] "v"(XV(8)), [x9] "v"(XV(9)));
                 }
+#undef XV
+            } else if constexpr (g == 6) {
+                float c0, c1;
+                asm volatile(F64_MFMA_S F64_CHAIN1 : [d] "+v"(sn[bk][tt]), [mx0] "+v"(mx[0]), [mx1] "+v"(mx[1]), [t0] "=&v"(c0), [t1] "=&v"(c1)
+                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [sc] "s"(scale_log2e));
+            } else {
+                float c0, c1;
+                unsigned long long k1;
+                asm volatile(F64_MFMA_S F64_CHAIN2 : [d] "+v"(sn[bk][tt]), [m0] "+v"(m_run[0]), [m1] "+v"(m_run[1]), [t0] "=&v"(c0), [t1] "=&v"(c1), [k0] "=&s"(need), [k1] "=&s"(k1)
+                             : [a] "v"(fa[cur][tt]), [b] "a"(qf[bk][ks]), [mx0] "v"(mx[0]), [mx1] "v"(mx[1]), [thr] "s"(RESCALE_THR) : "scc");
             }
-        }
-        // ---- gaps 8-55: P(j) spread over the score MFMAs of k steps 2-7 and the product MFMAs of key slabs 0-2; gaps 56-63: slab 3
+        });
+        F64_STAMP(1);                                             // gaps 0-7
+        // ---- gaps 8-55: P(j) spread over the score MFMAs of k steps 2-7 and the product MFMAs of key slabs 0-2; gaps 56-63: slab 3.
+        // In front of the first product MFMA (gap 32), out of line and rare: the rescale of O and l (O is complete through tile j-1).
         float ps[2] = {0.f, 0.f};
-        const float negm[2] = {-m_run[0], -m_run[1]};
         uint32_t pw[2][4][4];                                     // P(j): [block][key slab][word]
         float t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;             // the two pairs in flight
-        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &negm, &t0, &t1, &u0, &u1, &frag, &dma_piece, kl, vl, t_dma, k_dma, v_dma, scale_log2e](auto gc) {
+        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &frag, &dma_piece, kl, vl, t_dma, k_dma, v_dma, scale_log2e](auto gc) {
             constexpr int g = decltype(gc)::value + 8;
+            if constexpr (g == 32) {
+                if (need) {                                       // wave-uniform
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const float alpha = __builtin_amdgcn_exp2f(m_old[rb] - m_run[rb]);
+                        l_run[rb] *= alpha;
+#pragma unroll
+                        for (int rd = 0; rd < 4; ++rd) {
+                            // the empty volatile statement "redefines" the accumulator inside this block: without it hipcc copies all 128 O
+                            // registers out of the accumulator file ABOVE the branch, on every tile
+                            asm volatile("" : "+a"(o[rb][rd]));
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[rb][rd][r] *= alpha;
+                        }
+                    }
+                }
+            }
             constexpr bool is_qk = g < 32;
             constexpr int q4 = g & 3, bk = q4 & 1, hf = q4 >> 1;                           // block, key half (scores) / d tile parity (product)
             constexpr int ks = is_qk ? (g >> 2) : 0;                                        // score MFMA: k step
@@ -542,10 +593,10 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                 if constexpr (is_qk) {
                     if constexpr (ph == 0)
                         asm volatile(F64_MFMA_S F64_EXP_A : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [nm] "v"(negm[xb]));
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [m] "v"(m_run[xb]));
                     else if constexpr (ph == 1)
                         asm volatile(F64_MFMA_S F64_EXP_B : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [u0] "=&v"(u0), [u1] "=&v"(u1)
-                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [nm] "v"(negm[yb]));
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [m] "v"(m_run[yb]));
                     else
                         asm volatile(F64_MFMA_S F64_EXP_C : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
                                      : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [u0] "v"(u0));
@@ -553,16 +604,17 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
                     if constexpr (ph == 0)
                         asm volatile(F64_MFMA_S F64_EXP_A : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [nm] "v"(negm[xb]));
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [x0] "v"(xs0), [x1] "v"(xs1), [sc] "s"(scale_log2e), [m] "v"(m_run[xb]));
                     else if constexpr (ph == 1)
                         asm volatile(F64_MFMA_S F64_EXP_B : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [u0] "=&v"(u0), [u1] "=&v"(u1)
-                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [nm] "v"(negm[yb]));
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [m] "v"(m_run[yb]));
                     else
                         asm volatile(F64_MFMA_S F64_EXP_C : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
                                      : [a] "v"(fa[cur][hf]), [b] "v"(pf), [u0] "v"(u0));
                 }
             }
         });
+        F64_STAMP(3);                                             // gaps 8-63
         l_run[0] += ps[0];
         l_run[1] += ps[1];
         adv(k_cur, K_RING); adv(k_dma, K_RING); adv(v_cur, V_RING); adv(v_dma, V_RING);
@@ -573,6 +625,11 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         tile_body(j + 1, sB, sA);
     }
 
+#ifdef F64_PROF
+    if (blockIdx.x == 1000 && tid == 0)
+        printf("F64_PROF tiles %d: wait+barrier %llu, gaps0-7 %llu, decision %llu, gaps8-63 %llu cycles per tile (s_memtime units)\n", n_tiles,
+               prof[0] / n_tiles, prof[1] / n_tiles, prof[2] / n_tiles, prof[3] / n_tiles);
+#endif
     // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3
 #pragma unroll
     for (int bk = 0; bk < 2; ++bk) {

@@ -1,7 +1,5 @@
-// Device helpers shared by the decode dense kernels (decode_fused.hip: one launch per phase) and the dataflow layer kernel
-// (decode_flow.hip: one launch per layer): residual rows -> RMSNorm -> LDS X image, non-temporal weight slices, the streamed
-// fragment -> MFMA operand conversion (bf16 / e4m3) and the split-K MFMA loop.  Both users run EXACTLY these functions, so a
-// quantity computed by either path has the same bits.
+// Device helpers of the decode dense kernels (decode_fused.hip): residual rows -> RMSNorm -> LDS X image, non-temporal weight slices,
+// the streamed fragment -> MFMA operand conversion (bf16 / e4m3) and the split-K MFMA loop.
 #pragma once
 #include "common.h"
 #include "decode_layout.h"

@@ -178,12 +178,8 @@ struct DotsEngine {
     int out_cap = 0;                       // row stride of out_ids for the current generation
     bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
-    // decode layer launch plan: 0 = one launch per phase, 1 = [qkv -> attention] and [o_proj -> gate|up] fused (decode_flow.hip; B <= 8),
-    // 2 = one launch per phase with the half-chip plan (whole-tile projections) on every step
-    int flow_mode = 0;
-    bf16_t* d_qkvn = nullptr;              // [max_batch][(Hq + 2 Hkv) * 128]: q | k | v of the token of this step
-    uint32_t *flow_sync = nullptr, *flow_err = nullptr;
-    size_t flow_sync_bytes = 0;
+    // decode launch plan forced on every step (dots_set_decode_plan): 0 = by stream (whole chip / CU partition), 1 = always the partition plan
+    int force_part = 0;
     int B = 0;                             // sequences of the current batch
     int B_sel = 0;                         // rows the token-selection kernel runs over
     // ---- continuous batching: every sequence slot b < max_batch is free or occupied; the decode graph runs over rows
@@ -558,12 +554,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_logits, (size_t)mb * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
-    CK(e->alloc(&e->d_qkvn, (size_t)mb * (c.num_heads + 2 * c.num_kv_heads) * 128));
-    e->flow_sync_bytes = flow_sync_bytes_per_layer() * c.num_layers;
-    CK(e->alloc(&e->flow_sync, e->flow_sync_bytes / 4));
-    CK(e->alloc(&e->flow_err, (size_t)16));
-    CK(hipMemsetAsync(e->flow_err, 0, 64, e->stream));
-    if (const char* fm = getenv("DOTS_OCR_FLOW")) e->flow_mode = std::max(0, std::min(2, atoi(fm)));
+    if (const char* fm = getenv("DOTS_OCR_DECODE_PLAN")) e->force_part = atoi(fm) ? 1 : 0;
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
     // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
     e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
@@ -1006,25 +997,11 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
     const int B = e->B;
     const float scale = 1.0f / sqrtf(128.0f);
     CK(launch_dec_embed(s, e->cur_tokens, e->embed, e->d_h, B, H));
-    const bool flow = e->flow_mode == 1 && flow_supported(B, H, Hq, Hkv, I);
-    if (e->flow_mode == 2) part = 1;                                               // dots_set_decode_flow(2): the partition plan on every step (tests, A/B runs)
-    if (flow) CK(hipMemsetAsync(e->flow_sync, 0, e->flow_sync_bytes, s));         // a memset node at the head of every replay
+    if (e->force_part) part = 1;                                                   // dots_set_decode_plan(1): the partition plan on every step (tests, A/B runs)
     static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
     for (int i = 0; i < c.num_layers; ++i) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
-        if (flow) {
-            FlowLayerArgs A{};
-            A.h = e->d_h; A.qkvn = e->d_qkvn; A.part_o = e->d_part_o; A.part_ml = e->d_part_ml; A.att = e->d_att; A.act = e->d_act;
-            A.inv_freq = e->lm_inv_freq; A.ctx_len = e->ctx_len; A.block_table = e->block_table; A.err = e->flow_err;
-            A.sync = e->flow_sync + (flow_sync_bytes_per_layer() / 4) * i;
-            A.max_pages = e->max_pages; A.B = B; A.H = H; A.Hq = Hq; A.Hkv = Hkv; A.I = I; A.n_splits = n_splits;
-            A.eps = c.rms_norm_eps; A.scale = scale;
-            A.ln1 = L.ln1; A.ln2 = L.ln2; A.qkv_b = L.qkv_b; A.qkv_w = L.qkv_wd; A.o_w = L.o_wd; A.w13 = L.w13_wd; A.down_w = L.down_wd;
-            A.qkv_s = L.qkv_s; A.o_s = L.o_s; A.w13_s = L.w13_s; A.down_s = L.down_s; A.pool = pool_l;
-            CK(launch_decode_layer_flow(s, 1, A));
-            continue;
-        }
         CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
                           Hkv, c.rms_norm_eps, part));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
@@ -1041,18 +1018,6 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
 }
 
 int splits_for_ctx(int max_ctx) { return decode_attn_splits(max_ctx); }
-
-// A hand-off of the dataflow layer kernel gave up (bounded spin): the step's results are garbage — fail loudly.  Called where the
-// host synchronises with the stream anyway.
-int flow_check(DotsEngine* e) {
-    if (!e->flow_err || e->flow_mode == 0) return DOTS_OK;
-    uint32_t v = 0;
-    CK(hipMemcpyAsync(&v, e->flow_err, 4, hipMemcpyDeviceToHost, e->stream));
-    CK(hipStreamSynchronize(e->stream));
-    if (!v) return DOTS_OK;
-    CK(hipMemsetAsync(e->flow_err, 0, 4, e->stream));
-    return e->fail(DOTS_E_HIP, "decode dataflow layer: an in-launch hand-off timed out (set DOTS_OCR_FLOW=0 for the launch-per-phase kernels)");
-}
 
 // The captured decode step for (rows = e->B, splits, out_cap, e->n_eos): looked up in the cache or captured now.
 int step_graph(DotsEngine* e, int rows, int n_splits, int out_cap, hipGraphExec_t* exec, int part = 0) {
@@ -1333,7 +1298,7 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     hipGraphExec_t exec_part = nullptr;            // the step captured with the half-chip launch plan, for the masked stream
     if (use_graph && max_new_tokens > 1) {
         if (e->step_graphs.size() >= 30) drop_step_graphs(e);          // so that neither lookup below can evict the other's graph
-        if (e->s_vit && e->flow_mode == 0) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
+        if (e->s_vit) RET(step_graph(e, B, n_splits, max_new_tokens, &exec_part, 1));
         RET(step_graph(e, B, n_splits, max_new_tokens, &exec));
     }
     std::vector<int32_t> fin(DOTS_MAX_BATCH);
@@ -1361,7 +1326,6 @@ int dots_generate(DotsEngine* e, const int32_t* input_ids, const int32_t* prompt
     CK(hipMemcpyAsync(tmp.data(), e->out_ids, tmp.size() * 4, hipMemcpyDeviceToHost, s));
     CK(hipMemcpyAsync(out_lens, e->out_lens, B * 4, hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
-    RET(flow_check(e));
     std::memcpy(out_ids, tmp.data(), tmp.size() * 4);
 
     // ---- stats
@@ -1470,7 +1434,7 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
     // half-chip launch plan when the rows allow it — exactly as dots_generate does
     hipStream_t cur = s;
     if (use_graph) { int r0 = pick_decode_stream(e, &cur); if (r0 != DOTS_OK) { e->B = 0; return r0; } }
-    const int part = (cur != s && e->flow_mode == 0) ? 1 : 0;
+    const int part = cur != s ? 1 : 0;
     hipGraphExec_t exec = nullptr;
     if (use_graph) {
         int r = step_graph(e, rows, n_splits, 0, &exec, part);
@@ -1494,7 +1458,6 @@ int dots_slots_poll(DotsEngine* e, int32_t* finished, int32_t* out_lens) {
     CK(hipMemcpyAsync(finished, e->finished, mb * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipMemcpyAsync(out_lens, e->out_lens, mb * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipStreamSynchronize(e->stream));
-    RET(flow_check(e));
     for (int b = 0; b < mb; ++b) {
         if (!e->slot_mode || !e->slot_active[b]) { finished[b] = -1; out_lens[b] = 0; }      // -1: free slot
         else if (finished[b]) e->slot_done[b] = 1;                                           // takes no more pages
@@ -1633,11 +1596,11 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
     return DOTS_OK;
 }
 
-int dots_set_decode_flow(DotsEngine* e, int mode) {
+int dots_set_decode_plan(DotsEngine* e, int plan) {
     if (!e) return DOTS_E_INVALID;
-    if (mode < 0 || mode > 2) return e->fail(DOTS_E_INVALID, "decode flow mode must be 0, 1 or 2");
-    if (mode != e->flow_mode) {
-        e->flow_mode = mode;
+    if (plan < 0 || plan > 1) return e->fail(DOTS_E_INVALID, "decode plan must be 0 (by stream) or 1 (partition plan on every step)");
+    if (plan != e->force_part) {
+        e->force_part = plan;
         drop_step_graphs(e);                               // the captured decode steps bake the launch plan in
     }
     return DOTS_OK;
@@ -1649,7 +1612,6 @@ int dots_get_logits(DotsEngine* e, float* out) {
     CK(hipSetDevice(e->device));
     CK(hipMemcpyAsync(out, e->d_logits, (size_t)e->B * e->cfg.vocab_size * 4, hipMemcpyDeviceToHost, e->stream));
     CK(hipStreamSynchronize(e->stream));
-    RET(flow_check(e));
     return DOTS_OK;
 }
 

@@ -59,29 +59,6 @@ hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w,
                              int B, int H, int I, float eps, int part_cus = 0);
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
                              int B, int H, int V, float eps);
-// ---- decode_flow.hip: the decoder layer of the decode step as [qkv -> attention] | combine | [o_proj -> gate|up] | down_proj: the two
-// pairs are ONE launch each, chained by an in-launch hand-off (B <= 8).  Weight operands as for the launch_dec_* launchers (wscale
-// pointers nullptr = bf16).
-struct FlowLayerArgs {
-    bf16_t* h;                 // [B][H] residual stream, updated in place
-    bf16_t* qkvn;              // [B][(Hq + 2 Hkv) * 128] scratch: q | k | v of this step's token
-    float *part_o, *part_ml;   // split-KV partials (sized as for launch_decode_attn)
-    bf16_t *att, *act;         // X images [Nq/8][8][8], [I/8][8][8]
-    const float* inv_freq;
-    const int32_t *ctx_len, *block_table;
-    uint32_t* err;             // set to 1 by a hand-off that timed out
-    uint32_t* sync;            // flow_sync_bytes_per_layer() bytes of this layer, zeroed since the last use
-    int max_pages, B, H, Hq, Hkv, I, n_splits;
-    float eps, scale;
-    const bf16_t *ln1, *ln2, *qkv_b;
-    const void *qkv_w, *o_w, *w13, *down_w;
-    const float *qkv_s, *o_s, *w13_s, *down_s;
-    bf16_t* pool;              // this layer's KV pages
-};
-size_t flow_sync_bytes_per_layer();
-bool flow_supported(int B, int H, int Hq, int Hkv, int I);
-// what 1: the whole layer; 22 / 23: the first / second fused launch alone (tools/decode_bench)
-hipError_t launch_decode_layer_flow(hipStream_t s, int what, const FlowLayerArgs& A);
 int decode_attn_waves();                       // pages in flight per decode-attention workgroup (engine constant)
 int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,

@@ -158,14 +158,12 @@ int dots_preprocess_image(DotsEngine* e, const uint8_t* rgb, int rgb_on_device, 
  * parameters the reference passes to its vLLM backend (parser.py:27-28, model/inference.py:38-43).  Reproducible
  * from `seed` (counter-based: seed, batch slot, position). */
 int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t seed);
-/* Launch plan of the decode step for batches of <= 8 sequences (results are bit-identical in every mode): 1 = [qkv -> attention] and
- * [o_proj -> gate|up] as ONE launch each, the second phase chained to the first by an in-launch hand-off (csrc/decode_flow.hip);
- * 0 = one launch per phase (also what larger batches use); 2 = one launch per phase with the HALF-CHIP plan — qkv / o_proj / down_proj
- * as whole 16-row tiles, half as many workgroups — which dots_generate otherwise uses only while it replays the step on its 128-CU
- * partition beside a prefetched vision tower (there: 1.88 -> 1.67 ms per step; on the whole chip it is slower).  Environment
- * DOTS_OCR_FLOW sets the default.  A hand-off that times out
- * fails the call that next synchronises with DOTS_E_HIP — never a hang. */
-int dots_set_decode_flow(DotsEngine* e, int mode);
+/* Launch plan of the decode step (results are bit-identical under either plan).  0 (default) = chosen by where the step runs: the
+ * whole-chip plan (qkv / o_proj / down_proj as 8-row half tiles: 256 / 192 / 192 workgroups; one gate|up workgroup per tile pair), or —
+ * while the step is replayed on the decode CU partition beside a prefetched vision tower (dots_vit_prefetch) — the PARTITION plan: the
+ * projections as whole 16-row tiles (half as many workgroups) and gate|up as one resident round of workgroups that walk the tile pairs.
+ * 1 = the partition plan on every step (tests, A/B runs; slower on the whole chip).  Environment DOTS_OCR_DECODE_PLAN sets the default. */
+int dots_set_decode_plan(DotsEngine* e, int plan);
 
 /* ---- Continuous batching (the serving loop the reference delegates to vLLM: README "vLLM inference", parser.py:138-166
  * fires one request per page at it and the server keeps its batch full).  The engine's max_batch KV slots are

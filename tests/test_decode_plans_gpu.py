@@ -1,15 +1,14 @@
-"""Alternative launch plans of the decode step — mode 1: the fused decode launches (csrc/decode_flow.hip: [qkv -> attention] and [o_proj -> gate|up] as ONE launch each, the second role
-chained to the first by an in-launch hand-off) must produce EXACTLY the bits of the launch-per-phase kernels they replace
-(decode_fused.hip / decode.hip, parity-tested against the oracle in test_decode_kernels_gpu.py / test_fullsize_parity_gpu.py): same
-arithmetic, same reduction order, only the schedule and the transport of the activations differ.  Compared through the C ABI
-(dots_set_decode_flow): fp32 logits of every step, bitwise.
+"""The two launch plans of the decode step must produce EXACTLY the same bits: the whole-chip plan (qkv / o_proj / down_proj as 8-row half
+tiles, one gate|up workgroup per tile pair) and the PARTITION plan (whole 16-row tiles; gate|up as one resident round of workgroups that
+walk the tile pairs) that dots_generate / dots_slots_decode replay on the decode CU partition beside a prefetched vision tower — same
+arithmetic per element, only the work decomposition differs.  Compared through the C ABI (dots_set_decode_plan): fp32 logits of every
+step, bitwise.  (Rounds 3-4 also carried fused decode launches with in-launch hand-offs, experiments/decode_flow/: bit-identical,
+break-even, removed.)
 
-Edge cases the hand-offs add: the token of the step is patched into the prefetched last KV page from the q|k|v hand-off buffer
-(first / last key of a page, a page that starts with this token), sequences of different lengths in one batch (idle splits),
-contexts beyond 4 x 64 pages (a wave walks several pages), fp8 weights, repeated graph replays (the sync words are re-armed by
-the memset node of every replay), and a batch of 9 that must fall back to the launch-per-phase kernels.
-Mode 2: the half-chip plan (whole 16-row tiles in dec_qkv / dec_proj: what dots_generate replays on its 128-CU partition beside a
-prefetched vision tower) — the same bits as well.
+Cases: contexts that put the step's token at the last key of a page, the first key of a new page and in the middle; sequences of
+different lengths in one batch (idle KV splits); contexts beyond 4 x 64 pages (a wave walks several pages); fp8 weights; graph replay;
+9 and 20 rows (16-row X images, two batch tiles); the real dimensions, where the partition holds fewer gate|up workgroups (3 per CU x
+128 CUs) than there are tile pairs (560), so the walking path really runs.
 """
 import numpy as np
 import pytest
@@ -29,7 +28,7 @@ def _prompts(cfg, lens, seed):
 
 
 def _decode(eng, mode, ids, lens, n_steps):
-    eng.set_decode_flow(mode)
+    eng.set_decode_plan(mode)
     eng.prefill(ids, lens)
     logits, tokens = [eng.get_logits().copy()], [eng.get_last_tokens().copy()]
     for _ in range(n_steps):
@@ -58,35 +57,32 @@ def tiny():
 
 
 @pytest.mark.parametrize("lens", [[70], [63, 64, 65, 1, 127, 128, 200, 190], [5, 300, 61]])
-def test_flow_modes_equal_launch_per_phase_bitwise(tiny, lens):
-    """Contexts that put the step's token at the last key of a page, the first key of a new page and in the middle; 6 steps so that
-    several sequences cross a page boundary while decoding."""
+def test_partition_plan_equals_whole_chip_plan_bitwise(tiny, lens):
+    """6 steps so that several sequences cross a page boundary while decoding."""
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, lens, seed=len(lens))
     ref = _decode(eng, 0, ids, ln, 6)
-    for mode in (1, 2):
-        _assert_same(ref, _decode(eng, mode, ids, ln, 6), f"flow mode {mode}, prompt lengths {lens}")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 6), f"partition plan, prompt lengths {lens}")
 
 
-def test_flow_under_graph_replay_and_generate(tiny):
-    """dots_generate replays ONE captured graph: the memset node re-arms the hand-off words on every replay."""
+def test_plans_under_graph_replay_and_generate(tiny):
+    """dots_generate replays ONE captured graph per plan."""
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, [40, 90, 64, 33], seed=9)
     out = {}
-    for mode in (0, 1, 2):
-        eng.set_decode_flow(mode)
+    for mode in (0, 1):
+        eng.set_decode_plan(mode)
         out[mode] = eng.generate(ids, ln, max_new_tokens=80)
-    for m in (1, 2):
-        for a, b in zip(out[0], out[m]):
-            assert np.array_equal(np.asarray(a), np.asarray(b))
+    eng.set_decode_plan(0)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
-def test_batch_of_nine_falls_back(tiny):
+def test_batch_of_nine(tiny):
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, [20 + 3 * i for i in range(9)], seed=2)
     ref = _decode(eng, 0, ids, ln, 3)
-    _assert_same(ref, _decode(eng, 1, ids, ln, 3), "B = 9 (launch-per-phase fallback)")
-    _assert_same(ref, _decode(eng, 2, ids, ln, 3), "B = 9, partition plan (16-row X image)")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 3), "B = 9, partition plan (16-row X image)")
 
 
 def test_partition_plan_above_16_rows_bitwise():
@@ -99,11 +95,11 @@ def test_partition_plan_above_16_rows_bitwise():
     eng.load_state_dict(sd)
     ids, ln = _prompts(cfg, [17 + 11 * i for i in range(20)], seed=13)
     ref = _decode(eng, 0, ids, ln, 4)
-    _assert_same(ref, _decode(eng, 2, ids, ln, 4), "B = 20, partition plan")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 4), "B = 20, partition plan")
     eng.close()
 
 
-def test_flow_walks_several_pages_per_wave_beyond_16k_context():
+def test_plans_walk_several_pages_per_wave_beyond_16k_context():
     """max_seq_len > 16 384 caps the KV split at 64 workgroups of 4 waves: a wave then walks pages p, p + 256, ..."""
     from dots_ocr_amd.engine import Engine
     cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
@@ -112,12 +108,11 @@ def test_flow_walks_several_pages_per_wave_beyond_16k_context():
     eng.load_state_dict(sd)
     ids, ln = _prompts(cfg, [16500, 16383], seed=4)
     ref = _decode(eng, 0, ids, ln, 3)
-    for mode in (1, 2):
-        _assert_same(ref, _decode(eng, mode, ids, ln, 3), f"16.5k-token contexts, mode {mode}")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 3), "16.5k-token contexts, partition plan")
     eng.close()
 
 
-def test_flow_fp8_equals_launch_per_phase_bitwise():
+def test_partition_plan_fp8_bitwise():
     from dots_ocr_amd.engine import Engine
     cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
     sd = random_state_dict(cfg, seed=7)
@@ -126,18 +121,12 @@ def test_flow_fp8_equals_launch_per_phase_bitwise():
     ids, ln = _prompts(cfg, [64, 100, 31], seed=8)
     ref = _decode(eng, 0, ids, ln, 5)
     ref2 = _decode(eng, 0, ids, ln, 5)
-    _assert_same(ref, ref2, "fp8, launch-per-phase run twice")
-    for mode in (1, 2):
-        got = _decode(eng, mode, ids, ln, 5)
-        for s_, (a, b) in enumerate(zip(ref[0], got[0])):
-            bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
-            if len(bad):
-                print(f"fp8 mode {mode} step {s_}: {len(bad)} logits differ, rows {sorted(set(bad[:, 0].tolist()))}, max |d| {np.abs(a - b).max():.3e}")
-        _assert_same(ref, got, f"fp8, flow mode {mode}")
+    _assert_same(ref, ref2, "fp8, whole-chip plan run twice")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 5), "fp8, partition plan")
     eng.close()
 
 
-def test_flow_at_the_real_dimensions_bitwise():
+def test_plans_at_the_real_dimensions_bitwise():
     """dots.ocr's LM dimensions (H 1536, 12:2 heads, I 8960, vocab 151 936; 4 layers of seeded random weights cover every role at its
     real shape): B = 8, one context of 5.2 k tokens (25 KV splits like the bench) beside short ones that sit on, before and after a
     page boundary; 5 steps."""
@@ -151,6 +140,5 @@ def test_flow_at_the_real_dimensions_bitwise():
     eng.load_state_dict(sd)
     ids, ln = _prompts(cfg, lens, seed=3)
     ref = _decode(eng, 0, ids, ln, 5)
-    for mode in (1, 2):
-        _assert_same(ref, _decode(eng, mode, ids, ln, 5), f"real dimensions, flow mode {mode}")
+    _assert_same(ref, _decode(eng, 1, ids, ln, 5), "real dimensions, partition plan")
     eng.close()

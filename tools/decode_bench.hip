@@ -24,7 +24,6 @@ static hipStream_t S;
 #ifdef DOTS_TRACE
 void dots_trace_set_fused(unsigned long long* buf);
 void dots_trace_set_decode(unsigned long long* buf);
-void dots_trace_set_flow(unsigned long long* buf);
 static unsigned long long* g_trace = nullptr;
 constexpr size_t TRACE_WORDS = (size_t)4096 * 16 * 8;
 // per-slot statistics of the LAST launch that wrote the trace buffer: offsets in us from the earliest slot-0 stamp
@@ -50,31 +49,6 @@ static void trace_report(const char* name, int n_slots) {
 static void trace_report(const char*, int) {}
 #endif
 
-#ifdef DOTS_TRACE
-// flow kernel: slots per (global block, wave): [(gblk * 4 + wave) * 8 + slot]; per-role statistics relative to the earliest stamp of the launch
-static void flow_trace_report(const int* seg, int n_roles = 6, const char* const* names = nullptr) {
-    std::vector<unsigned long long> h(TRACE_WORDS);
-    CK(hipMemcpy(h.data(), g_trace, TRACE_WORDS * 8, hipMemcpyDeviceToHost));
-    unsigned long long t0 = ~0ull;
-    for (size_t w = 0; w < TRACE_WORDS / 8; ++w) if (h[w * 8]) t0 = std::min(t0, h[w * 8]);
-    const char* rn0[] = {"qkv", "attn", "comb", "o", "gateup", "down"};
-    const char* const* rn = names ? names : rn0;
-    for (int r = 0; r < n_roles; ++r) {
-        printf("    trace role %-7s", rn[r]);
-        for (int sl = 0; sl < 7; ++sl) {
-            double sum = 0, mx = 0, mn = 1e30; size_t n = 0;
-            for (size_t w = (size_t)seg[r] * 4; w < (size_t)seg[r + 1] * 4; ++w) {
-                if (!h[w * 8 + sl]) continue;
-                const double us = (double)(h[w * 8 + sl] - t0) * 0.01;
-                sum += us; mx = std::max(mx, us); mn = std::min(mn, us); ++n;
-            }
-            if (n) printf("  [%d] %.2f/%.2f/%.2f", sl, mn, sum / n, mx);
-        }
-        printf("\n");
-    }
-    CK(hipMemset(g_trace, 0, TRACE_WORDS * 8));
-}
-#endif
 static double time_graph(const std::function<void()>& body, int reps = 5) {
     hipGraph_t g; hipGraphExec_t ex;
     CK(hipStreamBeginCapture(S, hipStreamCaptureModeThreadLocal));
@@ -117,7 +91,6 @@ int main(int argc, char** argv) {
     CK(hipMemset(g_trace, 0, TRACE_WORDS * 8));
     dots_trace_set_fused(g_trace);
     dots_trace_set_decode(g_trace);
-    dots_trace_set_flow(g_trace);
 #endif
     const int max_pages = (max_seq + 63) / 64;
     const int n_splits = decode_attn_splits(max_seq);
@@ -182,26 +155,6 @@ int main(int argc, char** argv) {
         CK(launch_argmax_step(S, logits, V, V, B, am_val, am_idx, st));
     };
     auto step = [&]() { step_skip(0); };
-    // fused pairs (decode_flow.hip): 1 = the whole step, 22 / 23 = one of the fused launches alone, per layer
-    bf16_t* qkvn = dalloc<bf16_t>((size_t)16 * NQKV);
-    const size_t sync_l = flow_sync_bytes_per_layer();
-    uint32_t* fsync = dalloc<uint32_t>(sync_l * L / 4);
-    uint32_t* ferr = dalloc<uint32_t>(16);
-    auto step_flow = [&](int mode) {
-        if (mode < 10) CK(launch_dec_embed(S, cur, embed, h0, B, H));
-        CK(hipMemsetAsync(fsync, 0, sync_l * L, S));
-        for (int i = 0; i < L; ++i) {
-            FlowLayerArgs A{};
-            A.h = h0; A.qkvn = qkvn; A.part_o = po; A.part_ml = pml; A.att = att; A.act = act; A.inv_freq = inv_freq; A.ctx_len = ctx_len; A.block_table = tab;
-            A.err = ferr; A.sync = fsync + (sync_l / 4) * i; A.max_pages = max_pages; A.B = B; A.H = H; A.Hq = Hq; A.Hkv = Hkv; A.I = I; A.n_splits = n_splits;
-            A.eps = eps; A.scale = scale; A.ln1 = ln1[i]; A.ln2 = ln2[i]; A.qkv_b = bias[i]; A.qkv_w = qkv[i]; A.o_w = o[i]; A.w13 = w13[i]; A.down_w = down[i];
-            A.qkv_s = wsc; A.o_s = wsc; A.w13_s = wsc; A.down_s = wsc; A.pool = pool + pool_layer * i;
-            CK(launch_decode_layer_flow(S, mode, A));
-        }
-        if (mode >= 10) return;
-        k_lm();
-        CK(launch_argmax_step(S, logits, V, V, B, am_val, am_idx, st));
-    };
     const double w_bytes = (double)wb * (L * ((double)NQKV * H + (double)Nq * H + 3.0 * H * I) + (double)V * H);
     const double kv_bytes = (double)B * (ctx + 1) * L * Hkv * 128 * 2 * 2;
     printf("decode_bench: B=%d ctx=%d max_seq_len=%d (n_splits %d); algorithmic bytes/step %.1f MB weights + %.1f MB KV\n", B, ctx, max_seq, n_splits,
@@ -214,37 +167,6 @@ int main(int argc, char** argv) {
     const double t_step = time_graph(step);
     printf("whole step              %9.1f us   %.2f TB/s algorithmic (%.1f %% of 8 TB/s)\n", t_step, (w_bytes + kv_bytes) / t_step / 1e6,
            (w_bytes + kv_bytes) / t_step / 1e6 / 8 * 100);
-    if (flow_supported(B, H, Hq, Hkv, I)) {
-        {
-            const double t = time_graph([&]() { step_flow(1); });
-            uint32_t e = 0;
-            CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
-            printf("whole step, fused pairs  %9.1f us   %.2f TB/s algorithmic (%.1f %% of 8 TB/s)%s\n", t, (w_bytes + kv_bytes) / t / 1e6,
-                   (w_bytes + kv_bytes) / t / 1e6 / 8 * 100, e ? "   !! HAND-OFF TIMEOUT" : "");
-            CK(hipMemset(ferr, 0, 4));
-        }
-        printf("  [qkv -> attention] one launch    %8.2f us   (separate: dec_qkv + decode_attn below)\n", time_graph([&]() { step_flow(22); }) / L);
-        printf("  [o_proj -> gate|up] one launch   %8.2f us   (separate: dec_proj o + dec_gateup below)\n", time_graph([&]() { step_flow(23); }) / L);
-#ifdef DOTS_TRACE
-        {
-            const char* na[] = {"qkv", "attn"};
-            const char* nb[] = {"o", "gateup"};
-            int sa[3] = {0, (Hq + 2 * Hkv) * 8, (Hq + 2 * Hkv) * 8 + n_splits * Hkv * B};
-            int sb[3] = {0, H / 8, H / 8 + I / 16};
-            CK(hipMemset(g_trace, 0, TRACE_WORDS * 8));
-            time_graph([&]() { step_flow(22); }, 1);
-            printf("  timeline (last layer's launch; min/mean/max us over waves)  qkv: 0 start 1 rows in 2 norm done 3 mfma 4 stored 5 drained 6 arrived | attn: 0 start 1 READY seen (wave 0) 2 q in LDS 3 pages done 4 partials stored\n");
-            flow_trace_report(sa, 2, na);
-            time_graph([&]() { step_flow(23); }, 1);
-            printf("  o: 0 start 1 mfma done 4 stored 5 drained | gateup: 0 start 1 READY seen (wave 0) 2 rows in LDS 3 norm done 4 stored\n");
-            flow_trace_report(sb, 2, nb);
-        }
-#endif
-        uint32_t e = 0;
-        CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
-        if (e) printf("  !! HAND-OFF TIMEOUT in the single-launch runs\n");
-        if (getenv("DOTS_BENCH_FLOW_ONLY")) return 0;
-    }
     {
         const char* names[] = {"dec_qkv", "decode_attn", "decode_attn_combine", "dec_proj o", "dec_gateup", "dec_proj down", "dec_lmhead"};
         const double mbs[] = {wb * 1.0 * NQKV * H / 1e6, kv_bytes / L / 1e6, 0, wb * 1.0 * Nq * H / 1e6, wb * 2.0 * I * H / 1e6, wb * 1.0 * I * H / 1e6, wb * 1.0 * V * H / 1e6};
