@@ -54,6 +54,12 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="strictly sequential batches (ViT -> prefill -> decode); default: the tower of batch k+1 runs on a CU-masked side stream "
                          "while batch k decodes on the complementary CU partition (dots_vit_prefetch)")
+    ap.add_argument("--rows-in-flight", type=int, default=None,
+                    help="a4 / highres with overlap: decode rows in flight = how many page batches decode together (continuous batching over "
+                         "sequence slots, admission in groups of --batch pages).  Default 4 x batch (at most 32): the last four batches share every "
+                         "decode step (each weight byte is read once per 32 rows instead of once per 8) while the tower of the next batch runs on "
+                         "its CU partition; per timed step still exactly one preprocessing pass, one tower, one prefill and batch x max_new_tokens "
+                         "decoded tokens.  = batch: the round-3 pipeline (one batch decoding)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -211,8 +217,16 @@ def main():
     max_prompt = max(n_patches) // 4 + N_TEXT_TOKENS + 3
     max_seq = max_prompt + a.max_new_tokens + 64
     slots = B
+    overlap = not a.no_overlap and not mixed
+    rif = a.rows_in_flight if a.rows_in_flight is not None else (min(4 * B, 32) if overlap and a.workload in ("a4", "highres") else B)
+    deep = overlap and rif > B                      # several page batches decode together (sequence slots, admission in groups of B)
+    if deep and (rif % B or rif > 64):
+        raise SystemExit("--rows-in-flight must be a multiple of --batch, at most 64 (the engine's sequence slots)")
+    n_groups = rif // B if deep else 1
+    if deep:                                        # measured (profiles/r04_deep_sweep.txt): 32 rows decode on 64 CUs while the tower takes 192 — 4.90 pages/s;
+        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64" if a.workload == "a4" else "128")     # 96 / 160: 4.77; one batch on 128 / 128: 4.11
     max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
-    eng = Engine(cfg, device=local, max_batch=slots, max_seq_len=max_seq, max_patches=max_patches,
+    eng = Engine(cfg, device=local, max_batch=rif if deep else slots, max_seq_len=max_seq, max_patches=max_patches,
                  max_prefill_tokens=slots * max_prompt + 64, fp8_weights=fp8)
     eng.load_state_dict(sd)
     proc = DotsOcrProcessor(cfg, engine=eng)
@@ -249,8 +263,6 @@ def main():
         body = np.asarray(t_ids[1:-2][:N_TEXT_TOKENS - 2], np.int64)
         body = (body + rng.integers(0, 200, len(body))) % 256      # still byte ids
         return np.concatenate([h_ids, [cfg.image_token_id] * n_vis, t_ids[:1], body, t_ids[-2:]]).astype(np.int32)
-
-    overlap = not a.no_overlap and not mixed
 
     def preprocess_all():
         grids, off = [], 0
@@ -301,19 +313,71 @@ def main():
         host_ms["detokenize_ms"] += (t4 - t3) * 1e3
         return out, out_lens, texts, prompts
 
+    deep_state = {"k": 0, "queue": [], "last_decode_ms": 0.0}
+    half_steps = -(-a.max_new_tokens // n_groups)    # decode steps per timed step: a batch gets n_groups x half_steps >= max_new_tokens - 1 of them
+
+    def step_deep():
+        """One timed step of the two-batch pipeline: take the prefetched rows of batch k, preprocess batch k+1 and queue its tower behind
+        the prefill, prefill batch k into the free slot group, decode half_steps steps over BOTH groups (batch k: its first half, batch
+        k-1: its second half), read batch k-1 out.  Returns batch k-1's tokens (None while the pipeline fills)."""
+        k = deep_state["k"]
+        t0 = time.perf_counter()
+        prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
+        t1 = time.perf_counter()
+        eng.vit_take()
+        grids = preprocess_all()
+        t2 = time.perf_counter()
+        eng.vit_prefetch(pix_dev, np.asarray(grids, np.int64), on_device=True, after_prefill=True)
+        group = [(k % n_groups) * B + i for i in range(B)]
+        eng.slots_prefill(group, np.concatenate(prompts), [len(p) for p in prompts], [a.max_new_tokens] * B)
+        td = time.perf_counter()
+        done_steps = 0
+        while done_steps < half_steps:               # chunks: the decode stream (partition beside the tower / whole chip after it) is picked per chunk
+            n = min(64, half_steps - done_steps)
+            eng.slots_decode(n)
+            done_steps += n
+        fin, lens_ = eng.slots_poll()                # synchronises with the decode chain only (the tower of the next batch may still run)
+        deep_state["last_decode_ms"] = (time.perf_counter() - td) * 1e3
+        out = out_lens = texts = None
+        deep_state["queue"].append(group)
+        prev = deep_state["queue"].pop(0) if len(deep_state["queue"]) == n_groups else None
+        t3 = time.perf_counter()
+        if prev is not None:
+            assert all(fin[s_] == 1 for s_ in prev), "a batch did not finish within its two half loops"
+            out = np.zeros((B, a.max_new_tokens), np.int32)
+            out_lens = np.zeros(B, np.int32)
+            for i, s_ in enumerate(prev):
+                toks = eng.slot_read(s_, a.max_new_tokens)
+                out[i, :len(toks)], out_lens[i] = toks, len(toks)
+                eng.slot_release(s_)
+            texts = proc.batch_decode([out[i, :out_lens[i]] for i in range(B)])
+        t4 = time.perf_counter()
+        deep_state["k"] = k + 1
+        host_ms["tokenize_ms"] += (t1 - t0) * 1e3
+        host_ms["preprocess_ms"] += (t2 - t1) * 1e3
+        host_ms["detokenize_ms"] += (t4 - t3) * 1e3
+        return out, out_lens, texts, prompts
+
     seq_stats = None
     seq_out = None                                   # tokens of the strictly sequential batch: the pipelined steps decode the SAME pages
     pipelined_outs = []                              # (out, out_lens) of every pipelined step, compared after the timed region
     if overlap:
         # one strictly sequential batch first: warms everything up AND gives the per-kernel whole-chip timings of this very run
         # (reported beside the timed region's, where the tower and the decode loop share the chip); then the pipeline is primed
-        o0, l0, _, _ = step()
+        o0, l0, _, seq_prompts = step()
         seq_out = (o0.copy(), l0.copy())
         seq_stats = eng.stats()
+        if deep:
+            eng.set_eos([])
+            eng.slots_reset()                        # sequence-slot mode: every slot free, every KV page in the pool (drops any pending prefetch)
         eng.vit_prefetch(pix_dev, np.asarray(preprocess_all(), np.int64), on_device=True)
+        if deep:
+            for _ in range(n_groups - 1):
+                step_deep()                          # fills the pipeline (no batch completes yet); untimed
+    run_step = step_deep if deep else (lambda: step(overlap))
     for _ in range(a.warmup):
-        o_, l_, _, _ = step(overlap)
-        if overlap:
+        o_, l_, _, _ = run_step()
+        if overlap and o_ is not None:
             pipelined_outs.append((o_.copy(), l_.copy()))
     for k in host_ms:
         host_ms[k] = 0.0
@@ -321,11 +385,27 @@ def main():
     t0 = time.perf_counter()
     phase = {"vit_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "vit_attn_ms": 0.0}
     last = None
+    deep_bytes_per_step = 0.0
+    if deep:
+        # a static batch's decode_bytes = steps x W + kv_tok x sum over rows and steps of (context + 1): solve for W (every weight byte once per step)
+        kv_tok = cfg.num_hidden_layers * cfg.num_key_value_heads * 128 * 2 * 2
+        L0, st_n = len(seq_prompts[0]), seq_stats["decode_steps"]
+        W = (seq_stats["decode_bytes"] - kv_tok * sum(len(p) * st_n + st_n * (st_n + 1) // 2 for p in seq_prompts)) / st_n
+        ctx_sum = 0
+        for p in seq_prompts:                        # per timed step every page contributes its first half (steps 1..h) in one group and its second half in the other
+            ctx_sum += sum(len(p) + t + 1 for t in range(min(n_groups * half_steps, a.max_new_tokens - 1)))
+        deep_bytes_per_step = half_steps * W + kv_tok * ctx_sum
     for _ in range(a.steps):
-        out, out_lens, texts, prompts = step(overlap)
+        out, out_lens, texts, prompts = run_step()
         if overlap:
-            pipelined_outs.append((out, out_lens))   # a reference (generate returns fresh arrays): compared after the timed region
+            pipelined_outs.append((out, out_lens))   # a reference (fresh arrays every step): compared after the timed region
         st = eng.stats()                             # device-side HIP-event times of this step (static batches only)
+        if deep:                                     # slot mode records no decode events: wall time of this step's decode chunks (host-synchronised),
+            st = dict(st)                            # algorithmic bytes by the formula the engine uses for a static batch (weights once per step + KV read)
+            st["decode_ms"] = deep_state["last_decode_ms"]
+            st["decode_steps"] = half_steps
+            st["decode_bytes"] = deep_bytes_per_step
+            st["prefill_flops"] = seq_stats["prefill_flops"]
         for k in phase:
             phase[k] += st[k]
         last = st
@@ -403,7 +483,7 @@ def main():
         else:
             res["config"] = {"workload": f"{a.workload}: {B} pages/GPU of {size[0]}x{size[1]} px -> {n_patches[0]} patches, "
                                          f"{len(prompts[0])} prompt tokens/page, max_new_tokens={a.max_new_tokens}, EOS disabled",
-                             "pages_per_gpu": B, "parallelism": f"dp{world}"}
+                             "pages_per_gpu": B, "parallelism": f"dp{world}", "decode_rows_in_flight": rif if deep else B}
             def recorded(name, key):            # PMC numbers come from separate rocprofv3 --pmc passes over this same command
                 f = ROOT / "profiles" / name
                 if a.workload == "a4" and B == 8 and f.exists():
@@ -454,6 +534,12 @@ def main():
                             "after); per step exactly one preprocessing pass, one tower, one prefill, one decode loop; phase_ms_per_step therefore "
                             "OVERLAP and sum to more than ms_per_step" % (dec_cus, dec_cus - 1),
                     "dec_cus": dec_cus, "vit_cus": 256 - dec_cus,
+                    "batches_decoding_together": rif // B if deep else 1,
+                    "two_batch_pipeline": ("continuous batching over %d sequence slots with admission in groups of %d pages: a timed step takes the prefetched tower rows "
+                                           "of batch k, queues batch k+1's tower behind the prefill, prefills batch k into the free slot group and runs %d decode steps "
+                                           "over ALL groups (batch k: tokens 1-%d, the older batches their later parts), then reads the oldest batch out — every weight "
+                                           "byte is streamed once per %d rows instead of once per %d; a page's tokens do not depend on what shares its decode step "
+                                           "(bitwise check below)" % (rif, B, half_steps, half_steps, rif, B)) if deep else None,
                     "sequential_step_ms_same_run": seq_stats["total_ms"] if seq_stats else None,
                     "why": "two unmasked streams time-slice the chip (measured: no overlap); with complementary CU masks the MFMA-bound tower and the "
                            "latency-bound decode loop run side by side (tools/overlap_probe.py, profiles/r03_overlap_probe.txt)"}

@@ -73,3 +73,55 @@ class FakeSlotEngine:
 
     def slot_release(self, s):
         del self.slots[s]
+
+
+class FakePagedEngine(FakeSlotEngine):
+    """FakeSlotEngine + the paged KV pool of the real engine (engine.hip: reserve at admission, grow per decode chunk, lower the cap when
+    the pool runs dry — pages of P positions allow P + 1 tokens in all)."""
+    PAGE = 64
+
+    def __init__(self, script, pool_pages, **kw):
+        super().__init__(script, **kw)
+        self.pool_pages, self.free = pool_pages, pool_pages
+        self.capped = 0
+
+    def kv_pool_info(self):
+        return self.pool_pages, self.free
+
+    def slots_reset(self):
+        self.slots.clear()
+        self.free = self.pool_pages
+
+    def slots_prefill(self, slots, ids, lens, caps):
+        need = [(min(n + min(c, 64), self.max_seq_len) + 63) // 64 for n, c in zip(lens, caps)]
+        if sum(need) > self.free:
+            raise RuntimeError("KV pool exhausted")
+        super().slots_prefill(slots, ids, lens, caps)
+        for s, n, c, p in zip(slots, lens, caps, need):
+            self.slots[s].update(pages=p, limit=n + c, ctx=n)
+            self.free -= p
+
+    def slots_decode(self, n):
+        for st in self.slots.values():
+            if st["done"]:
+                continue
+            want = min(st["ctx"] + n, st["limit"] - 1)
+            while st["pages"] * self.PAGE < want and self.free > 0:
+                st["pages"] += 1
+                self.free -= 1
+            have = st["pages"] * self.PAGE
+            if have < want:
+                st["limit"] = have + 1
+                st["cap"] = have + 1 - len(st["prompt"])
+                self.capped += 1
+                if len(st["out"]) >= st["cap"]:
+                    st["done"] = True
+            st["ctx"] = min(st["ctx"] + n, st["limit"] - 1)
+        super().slots_decode(n)
+
+    def slot_capacity(self, s):
+        return self.slots[s]["pages"], self.slots[s]["limit"]
+
+    def slot_release(self, s):
+        self.free += self.slots[s]["pages"]
+        super().slot_release(s)

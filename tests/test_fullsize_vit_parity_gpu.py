@@ -12,7 +12,7 @@ The hub `DotsVisionTransformer.forward` the reference loads at dots_ocr/parser.p
     decode itself: max |logit error| vs the fp32 oracle <= 0.125, tokens equal wherever the emulated oracle's margin > 0.25;
   * the same page through an `fp8_weights` engine vs the fp8 oracle (quantised state dict, per-token e4m3 activations) AND vs
     the unquantised fp32 oracle: stated tolerances below, the measured numbers go to the report.
-Report: gpurun_out/r03_vit_fullwidth_parity.json (copied to profiles/ by hand).
+Report: gpurun_out/r04_vit_fullwidth_parity.json (copied to profiles/ by hand).
 """
 import json
 import os
@@ -48,7 +48,7 @@ def world():
     out = ROOT / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
-        (out / "r03_vit_fullwidth_parity.json").write_text(json.dumps(REPORT, indent=1))
+        (out / "r04_vit_fullwidth_parity.json").write_text(json.dumps(REPORT, indent=1))
     except OSError:
         pass
 
@@ -201,3 +201,62 @@ def test_fp8_engine_at_real_dimensions_vs_fp8_oracle_and_vs_the_unquantised_orac
     tol = max(0.04, 1.5 * w_oo)
     assert w_emu < tol and w_f32 < tol, f"engine {w_emu:.4f} / {w_f32:.4f} vs tolerance {tol:.4f}"
     assert w_unq < 0.25
+
+
+def test_fp8_engine_layer_by_layer_with_resynchronisation(world):
+    """VERDICT r3 #4b: the end-to-end fp8 comparison above passes by being inside the oracle's own noise (per-token e4m3 activation
+    quantisation is a step function; 70 layers amplify every flipped rounding), so it bounds nothing a kernel bug below ~14 % of the
+    logit range could do.  Here every layer is compared ON ITS OWN: the fp8 oracle computes vision block i / LM layer i from the
+    ENGINE's captured residual stream after block / layer i-1 (dots_debug_capture_hidden), so a flipped rounding cannot travel further
+    than the layer it happens in.  Tolerance back to the bf16 one: <= 3 % of the layer output's max magnitude, every layer."""
+    import copy
+    from dots_ocr_amd.engine import Engine
+    from dots_ocr_amd.synthetic import synth_prompt_ids
+    cfg, sd, sd32 = world
+    v = cfg.vision
+    pv, thw = _page(3, (583, 550))
+    N = pv.shape[0]
+    ids = synth_prompt_ids(cfg, N // 4, n_text_tokens=64, seed=3)
+    T = len(ids)
+    eng = Engine(cfg, max_batch=1, max_seq_len=T + 128, max_patches=N + 64, max_prefill_tokens=T + 64, fp8_weights=True)
+    eng.load_state_dict(sd)
+    eng.capture_hidden(v.num_hidden_layers * N * v.embed_dim + cfg.num_hidden_layers * T * cfg.hidden_size)
+    eng.vit_forward(pv, np.asarray([thw], np.int64))
+    eng.prefill(ids, np.asarray([T], np.int32))
+    eng.synchronize()
+    vit = [_bf(eng.read_hidden("vit", i)) for i in range(v.num_hidden_layers)]
+    lm = [_bf(eng.read_hidden("lm", i)) for i in range(cfg.num_hidden_layers)]
+    eng.close()
+    assert vit[0].shape == (N, v.embed_dim) and lm[0].shape == (T, cfg.hidden_size)
+
+    qsd = om.quantize_fp8_state_dict(sd32)
+    grid = torch.tensor([thw])
+    cos, sin = om.vision_rope_cos_sin(grid, v.head_dim, v.spatial_merge_size)
+    cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    rows_v, worst_v = [], 0.0
+    with torch.no_grad():
+        for i in range(1, v.num_hidden_layers):
+            ref = om.vision_block(qsd, f"vision_tower.blocks.{i}.", vit[i - 1], cos, sin, [N], v.num_attention_heads, v.head_dim, v.rms_norm_eps, True, a8=True)
+            err = float((vit[i] - ref).abs().max()) / float(ref.abs().max())
+            rows_v.append({"block": i, "max_err_over_max_magnitude": err})
+            worst_v = max(worst_v, err)
+        # LM prefill layers: a one-layer model whose layer 0 is layer i, fed the engine's stream after layer i-1
+        c1 = copy.deepcopy(cfg)
+        c1.num_hidden_layers = 1
+        rows_l, worst_l = [], 0.0
+        for i in range(1, cfg.num_hidden_layers):
+            sub = {k.replace(f"model.layers.{i}.", "model.layers.0."): t for k, t in qsd.items() if k.startswith(f"model.layers.{i}.")}
+            sub["model.norm.weight"] = qsd["model.norm.weight"]
+            sub["lm_head.weight"] = qsd["lm_head.weight"][:16]                       # the logits of this call are not used
+            _, hid = om.lm_forward(sub, c1, lm[i - 1], om.KVCache(1), emulate_bf16=True, return_hidden=True, a8=True)
+            err = float((lm[i] - hid[0]).abs().max()) / float(hid[0].abs().max())
+            rows_l.append({"layer": i, "max_err_over_max_magnitude": err})
+            worst_l = max(worst_l, err)
+    REPORT["fp8_layer_by_layer_resynchronised"] = {
+        "page": "583x550 (1 680 patches), prompt %d tokens" % T, "worst_vision_block": worst_v, "worst_lm_prefill_layer": worst_l,
+        "tolerance": "3 % of the layer output's max magnitude, every vision block 1-41 and every LM prefill layer 1-27, each computed by the fp8 oracle "
+                     "(bf16-emulated, per-token e4m3 activations) from the engine's own stream of the layer before",
+        "vision_blocks": rows_v, "lm_layers": rows_l}
+    print(f"fp8 layer by layer, re-synchronised: worst vision block {worst_v:.4f}, worst LM prefill layer {worst_l:.4f} of the layer's max magnitude")
+    assert worst_v < 0.03, f"vision block error {worst_v:.4f} >= 3 %: {max(rows_v, key=lambda r: r['max_err_over_max_magnitude'])}"
+    assert worst_l < 0.03, f"LM prefill layer error {worst_l:.4f} >= 3 %: {max(rows_l, key=lambda r: r['max_err_over_max_magnitude'])}"

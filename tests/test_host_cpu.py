@@ -659,3 +659,75 @@ def test_pdf_rasteriser_colour_modes_rotation_and_several_images_per_page():
     upright = np.rot90(page, 1)                           # undo: counter-clockwise
     assert (upright[:100, :, 0] == 250).all() and (upright[:100, :, 2] == 0).all()        # red strip on top
     assert (upright[100:, :, 2] == 250).all() and (upright[100:, :, 0] == 0).all()        # blue strip below
+
+
+def test_scheduler_surfaces_kv_truncation_and_full_reservation_never_truncates():
+    """with on-demand paging a dry pool ends a sequence at what its pages hold (P positions -> P + 1 tokens); the batcher
+    marks such requests `kv_truncated` (the server answers finish_reason "kv_pool_exhausted") and counts them; `headroom_pages=None`
+    is the full-reservation policy of rounds 1-2: fewer sequences in flight, nothing truncated."""
+    from fakes import FakePagedEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    script = lambda prompt: int(prompt[0]) * 1000 + np.arange(400)
+    mk = lambda: [Request(np.full(40, i, np.int32), None, None, 300) for i in range(1, 5)]          # 4 x (40 + 300) tokens = 4 x 6 pages by worst case
+    eng = FakePagedEngine(script, pool_pages=12, max_batch=4, max_patches=100, max_prefill_tokens=1 << 20, max_seq_len=1024)
+    cb = ContinuousBatcher(eng, chunk=8, headroom_pages=0)
+    reqs = mk()
+    outs = cb.run(reqs)
+    assert cb.kv_truncated >= 1 and eng.capped >= 1
+    for r, o in zip(reqs, outs):
+        pages_tokens = len(o) + 40 - 1                              # KV positions its tokens needed
+        if r.kv_truncated:
+            assert len(o) < 300 and pages_tokens % 64 == 0, (len(o),)           # ended exactly at what whole pages hold
+        else:
+            assert len(o) == 300
+        assert o.tolist() == (int(r.input_ids[0]) * 1000 + np.arange(len(o))).tolist()
+    assert eng.kv_pool_info() == (12, 12)
+    eng2 = FakePagedEngine(script, pool_pages=12, max_batch=4, max_patches=100, max_prefill_tokens=1 << 20, max_seq_len=1024)
+    cb2 = ContinuousBatcher(eng2, chunk=8, headroom_pages=None)
+    reqs2 = mk()
+    outs2 = cb2.run(reqs2)
+    assert cb2.kv_truncated == 0 and eng2.capped == 0 and all(len(o) == 300 for o in outs2) and not any(r.kv_truncated for r in reqs2)
+    assert max(len(x[2]) for x in eng2.log if x[0] == "decode") == 2              # 12 pages / 6 per sequence: two at a time
+
+
+def test_scheduler_keeps_failed_groups_findable_for_the_callers_error_handling():
+    """a request popped from `pending` must not vanish when the engine call that was to admit it raises — the server fails
+    the futures it finds in running / pending / _ahead, anything else hangs its HTTP request for ever."""
+    from fakes import FakeSlotEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+
+    class Failing(FakeSlotEngine):
+        fail_prefetch = fail_take = False
+        def vit_prefetch(self, *a, **k):
+            if self.fail_prefetch:
+                raise RuntimeError("tower launch failed")
+            return super().vit_prefetch(*a, **k)
+        def vit_take(self):
+            if self.fail_take:
+                raise RuntimeError("no rows")
+            return super().vit_take()
+    mk = lambda i: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), 20, tag=i)
+    eng = Failing(lambda prompt: int(prompt[0]) + np.arange(64), max_batch=2, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
+    cb = ContinuousBatcher(eng, chunk=4, prefetch=2)
+    for i in range(1, 5):
+        cb.submit(mk(i))
+    eng.fail_prefetch = True
+    with pytest.raises(RuntimeError, match="tower launch failed"):
+        cb.step()                       # admits 1, 2 — then the look-ahead for 3, 4 fails
+    assert sorted(r.tag for _, r in cb.pending) == [3, 4] and not cb._ahead
+    eng.fail_prefetch = False
+    cb.step()                            # look-ahead succeeds now
+    assert [r.tag for _, r in cb._ahead] == [3, 4]
+    eng.fail_take = True
+    with pytest.raises(RuntimeError, match="no rows"):
+        for _ in range(50):              # drain 1, 2; the admission of the prefetched group then fails at vit_take
+            cb.step()
+    assert not cb._ahead and sorted(r.tag for _, r in cb.pending) == [3, 4]
+    # a request that can never be admitted stays at the head of the queue when step() raises
+    eng3 = FakeSlotEngine(lambda prompt: np.arange(8), max_batch=1, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
+    cb3 = ContinuousBatcher(eng3)
+    cb3.pending.append((7, Request(np.zeros(80, np.int32), None, None, 4, tag="too long for max_prefill_tokens")))
+    cb3.plan_admission = lambda: []
+    with pytest.raises(RuntimeError, match="cannot be admitted"):
+        cb3.step()
+    assert len(cb3.pending) == 1

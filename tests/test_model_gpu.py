@@ -550,6 +550,43 @@ def test_kv_pages_grow_on_demand_admission_is_bounded_by_use_not_by_caps(setup):
     tiny_pool.close()
 
 
+@pytest.mark.parametrize("prompt_len,expect_new", [(56, 73), (50, 79), (63, 66)])
+def test_dry_pool_on_and_off_a_page_boundary_stops_the_row_inside_its_pages(setup, prompt_len, expect_new):
+    """a 2-page pool (128 KV positions) and one sequence that wants 200 tokens.  Pages of P positions allow P + 1
+    tokens in all (the last token needs no KV position).  With an 8-step chunk the pool runs dry either while the sequence sits exactly
+    AT its page boundary (prompt 56: context 128 = 2 pages when the next chunk is asked for — the row must be stopped on the device
+    before it writes position 128 through a block-table entry it does not own) or short of it (prompts 50, 63: the lowered cap ends
+    it).  Either way: exactly 128 + 1 - prompt tokens, a prefix of the free-running reference, the reported limit honoured, every page
+    returned."""
+    from dots_ocr_amd.engine import Engine
+    cfg, sd, eng = setup
+    rng = np.random.default_rng(prompt_len)
+    ids = rng.integers(0, cfg.vocab_size - 8, prompt_len).astype(np.int32)
+    ref, n = eng.generate(ids, np.array([prompt_len], np.int32), max_new_tokens=200)
+    ref = ref[0, :n[0]].tolist()
+    small = Engine(cfg, max_batch=2, max_seq_len=640, max_patches=256, max_prefill_tokens=1024, kv_pool_tokens=128)
+    small.load_state_dict(sd)
+    small.set_eos([])
+    small.slots_reset()
+    small.slots_prefill([0], ids, [prompt_len], [200])
+    for _ in range(30):
+        small.slots_decode(8)
+        fin, lens = small.slots_poll()
+        if fin[0] == 1:
+            break
+    assert fin[0] == 1, "the sequence never finished"
+    out = small.slot_read(0, 300).tolist()
+    pages, limit = small.slot_capacity(0)
+    assert len(out) == expect_new == 128 + 1 - prompt_len, (len(out), expect_new)
+    assert out == ref[:len(out)], "tokens past the owned pages were computed from another row's KV"
+    assert pages == 2 and limit == prompt_len + len(out)
+    small.slots_decode(8)                               # a finished row idles: nothing more is appended
+    assert small.slots_poll()[1][0] == len(out)
+    small.slot_release(0)
+    assert small.kv_pool_info() == (2, 2)
+    small.close()
+
+
 def test_static_batch_pages_are_returned_when_slot_mode_starts(setup):
     """a full-capacity static generate followed by continuous batching on the same engine must not leak the static
     batch's pages — the pool is whole again once the slots are released."""
