@@ -350,11 +350,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(
 // earliest; a score read by the softmax was written >= 32 MFMAs earlier; a P word is read by an MFMA >= 1 MFMA after the
 // v_cvt_pk that wrote it; MFMAs on the same accumulator are >= 3 MFMAs apart; the A operand of an MFMA comes from LDS (the compiler
 // places the lgkmcnt wait in front of the statement that uses it).
-// LDS: K ring 3 x 16 KiB (tiles j+1 .. j+3), V^T ring 4 x 16 KiB (tiles j .. j+3), swizzles as in the 8-wave kernel but applied on
-// the DMA source side (LDS-DMA writes lane-linear).  Tile j+3 is requested during tile j: two tile periods of cover.  K rows past a
-// sequence's end are read from the 64 spare rows the K buffer carries (kernels.h) and masked.
-constexpr int K_RING = 3, V_RING = 4;
-constexpr int RING_BYTES = (K_RING + V_RING) * KT_BYTES;      // KT_BYTES == VT_BYTES == 16 KiB
+// LDS: ONE ring of 4 stages, stage t % 4 = {K(t) 16 KiB | V^T(t) 16 KiB}, swizzles as in the 8-wave kernel but applied on the DMA source
+// side (LDS-DMA writes lane-linear).  The barrier of a tile sits in front of its LAST 8 gaps (product MFMAs of key slab 3, no softmax
+// work left): behind it the wave requests K(j+4) and V^T(j+3) — one DMA piece per gap, in gaps that have nothing else to carry — and
+// reads the first K fragments of tile j+1, so no tile starts with an exposed LDS round trip.  Two tile periods of cover for every
+// request.  K rows past a sequence's end are read from the 64 spare rows the K buffer carries (kernels.h) and masked.
+constexpr int RING = 4;
+constexpr int RING_BYTES = RING * 2 * KT_BYTES;               // KT_BYTES == VT_BYTES == 16 KiB
 
 #define F64_MFMA_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], 0\n\t"
 #define F64_MFMA_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
@@ -414,18 +416,23 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + ((size_t)hkv * T + qb.tok0) * 128), 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VT + (size_t)hkv * 128 * Tpad + qb.pad0), 0, 0x7ffffff0, 0x00020000);
     const int v_step = (int)(64 * Tpad);                          // bytes between d rows 32 apart
-    auto dma_piece = [&](int t, int kst, int vst, int i) {       // piece i of tile t: 0-3 K, 4-7 V^T
-        if (i < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + kst * KT_BYTES + (4 * i + w) * 1024), 16, k_src,
-                                                     (t * 64 + 16 * i) * 256, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + (K_RING + vst) * KT_BYTES + (4 * (i - 4) + w) * 1024), 16,
-                                                     v_src, t * 128 + (i - 4) * v_step, 0, 0);
+    auto dma_k = [&](int t, int i) {                            // piece i (0-3) of K(t) -> stage t % 4; t is clamped to the last tile
+        const int tc = min(t, t_last);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(smem + (t & 3) * 2 * KT_BYTES + (4 * i + w) * 1024), 16, k_src,
+                                                 (tc * 64 + 16 * i) * 256, 0, 0);
+    };
+    auto dma_v = [&](int t, int i) {                            // piece i (0-3) of V^T(t) -> stage t % 4
+        const int tc = min(t, t_last);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(smem + ((t & 3) * 2 + 1) * KT_BYTES + (4 * i + w) * 1024), 16,
+                                                 v_src, tc * 128 + i * v_step, 0, 0);
     };
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma_piece(min(t, t_last), t, t, i);
+        for (int i = 0; i < 4; ++i) {
+            dma_k(t, i);
+            if (t < 3) dma_v(t, i);
+        }
 
     f32x16 o[2][4];
 #pragma unroll
@@ -448,13 +455,10 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(uint32_t)((base ^ (x << 5)) + imm));
     };
 
-    // ring positions: K(j+1), V^T(j), and the stages tile j+3 goes to
-    int k_cur = 1, v_cur = 0, k_dma = 0, v_dma = 3;
-    auto adv = [&](int& x, int ring) { x = x + 1 == ring ? 0 : x + 1; };
 
     // ---- prologue: S(0)
     f32x16 sA[2][2], sB[2][2];                                   // S(j) / S(j+1): two VGPR sets, swapped every tile
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // Q and tile 0 (requested first) are in; tiles 1, 2 may fly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // once per workgroup: Q, K(0..3), V^T(0..2)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -472,20 +476,16 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
 #else
 #define F64_STAMP(i)
 #endif
+    bf16x8 fa[2][2];                                              // fragment pairs, one step ahead (carried from tile to tile)
+    fa[0][0] = frag(lds0 + k_lane + 2 * KT_BYTES, 0, 0);         // K(1), k step 0
+    fa[0][1] = frag(lds0 + k_lane + 2 * KT_BYTES, 0, 8192);
     // one tile: sc = S(j) (complete), sn <- S(j+1)
     auto tile_body = [&](int j, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) {
 #ifdef F64_PROF
         unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
-        // every wave's pieces of tile j+1 have landed (tile j+2's 8 may still fly) and every wave is done with the stages tile j+3 overwrites
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        F64_STAMP(0);                                             // wait + barrier
-        const int t_dma = min(j + 3, t_last);
-        const int kl = lds0 + k_lane + k_cur * KT_BYTES, vl = lds0 + v_lane + (K_RING + v_cur) * KT_BYTES;
-        bf16x8 fa[2][2];                                          // fragment pairs, one step ahead
-        fa[0][0] = frag(kl, 0, 0);
-        fa[0][1] = frag(kl, 0, 8192);
+        const int kl = lds0 + k_lane + ((j + 1) & 3) * 2 * KT_BYTES, vl = lds0 + v_lane + ((j & 3) * 2 + 1) * KT_BYTES;
+        // fa[0] = the first K fragments of this tile: read behind the previous tile's barrier
         const int key0 = j * 64;
         if (key0 + 64 > n) {                                      // ragged last tile / the padding tile of an odd count (rare): keys past the end
 #pragma unroll                                                    // hold whatever the spare K rows held -> -inf before the maxima see them
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         float ps[2] = {0.f, 0.f};
         uint32_t pw[2][4][4];                                     // P(j): [block][key slab][word]
         float t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;             // the two pairs in flight
-        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &frag, &dma_piece, kl, vl, t_dma, k_dma, v_dma, scale_log2e](auto gc) {
+        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &frag, &dma_k, &dma_v, kl, vl, j, lds0, k_lane, scale_log2e](auto gc) {
             constexpr int g = decltype(gc)::value + 8;
             if constexpr (g == 32) {
                 if (need) {                                       // wave-uniform
@@ -571,13 +571,28 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
             constexpr int ks = is_qk ? (g >> 2) : 0;                                        // score MFMA: k step
             constexpr int st = is_qk ? 0 : ((g - 32) >> 2), sl = st >> 1, dt = 2 * (st & 1) + hf;   // product MFMA: step, key slab, d tile
             constexpr int step = g >> 2, cur = step & 1;                                    // 16 steps of 4 MFMAs share 2 fragments
-            if constexpr (q4 == 0 && g < 60) {                                              // next step's fragments
+            if constexpr (g == 56) {
+                // The tile's barrier, in front of its last 8 gaps.  Before it: this wave's pieces of K(j+2) and V^T(j+1) — requested two tiles
+                // ago — have landed (the 8 pieces of the previous tile's tail may still fly).  Behind it every wave is done with K(j+1) and
+                // with V^T(j-1), K(j): the stages the requests of this tail overwrite; V^T(j) (key slab 3 is still to come) is not touched.
+#ifndef F64_NO_BAR
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+            if constexpr (q4 == 0) {                                                        // next step's fragments
                 constexpr int ns = step + 1;
                 if constexpr (ns < 8) { fa[cur ^ 1][0] = frag(kl, ns, 0); fa[cur ^ 1][1] = frag(kl, ns, 8192); }
-                else { constexpr int s2 = ns - 8; fa[cur ^ 1][0] = frag(vl, s2 >> 1, (2 * (s2 & 1)) * 4096); fa[cur ^ 1][1] = frag(vl, s2 >> 1, (2 * (s2 & 1) + 1) * 4096); }
+                else if constexpr (ns < 16) { constexpr int s2 = ns - 8; fa[cur ^ 1][0] = frag(vl, s2 >> 1, (2 * (s2 & 1)) * 4096); fa[cur ^ 1][1] = frag(vl, s2 >> 1, (2 * (s2 & 1) + 1) * 4096); }
+                else {                                                                      // g == 60: the first K fragments of the NEXT tile (K(j+2), visible since the barrier)
+                    const int kn = lds0 + k_lane + ((j + 2) & 3) * 2 * KT_BYTES;
+                    fa[cur ^ 1][0] = frag(kn, 0, 0);
+                    fa[cur ^ 1][1] = frag(kn, 0, 8192);
+                }
             }
 #ifndef F64_NO_DMA
-            if constexpr (g >= 10 && g <= 52 && (g - 10) % 6 == 0) dma_piece(t_dma, k_dma, v_dma, (g - 10) / 6);
+            if constexpr (g >= 56 && g < 60) dma_k(j + 4, g - 56);
+            if constexpr (g >= 60) dma_v(j + 3, g - 60);
 #endif
             if constexpr (g >= 56) {
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
@@ -617,7 +632,6 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         F64_STAMP(3);                                             // gaps 8-63
         l_run[0] += ps[0];
         l_run[1] += ps[1];
-        adv(k_cur, K_RING); adv(k_dma, K_RING); adv(v_cur, V_RING); adv(v_dma, V_RING);
     };
     // tiles in pairs (the two S sets swap roles); the extra tile of an odd count is fully masked (P = 0)
     for (int j = 0; j < n_tiles; j += 2) {
@@ -627,8 +641,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
 
 #ifdef F64_PROF
     if (blockIdx.x == 1000 && tid == 0)
-        printf("F64_PROF tiles %d: wait+barrier %llu, gaps0-7 %llu, decision %llu, gaps8-63 %llu cycles per tile (s_memtime units)\n", n_tiles,
-               prof[0] / n_tiles, prof[1] / n_tiles, prof[2] / n_tiles, prof[3] / n_tiles);
+        printf("F64_PROF tiles %d: gaps0-7 %llu, gaps8-63 %llu cycles per tile (s_memtime units)\n", n_tiles, prof[1] / n_tiles, prof[3] / n_tiles);
 #endif
     // ---- epilogue: O = O^T / l ; lane owns row q, d = dt*32 + 8*rq + 4*hi + 0..3
 #pragma unroll
