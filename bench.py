@@ -223,6 +223,8 @@ def main():
     if deep and (rif % B or rif > 64):
         raise SystemExit("--rows-in-flight must be a multiple of --batch, at most 64 (the engine's sequence slots)")
     n_groups = rif // B if deep else 1
+    if mixed:
+        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "96")      # look-ahead towers on 160 CUs beside up to 32 decoding rows on 96
     if deep:                                        # measured (profiles/r04_deep_sweep.txt): 32 rows decode on 64 CUs while the tower takes 192 — 4.90 pages/s;
         os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64" if a.workload == "a4" else "128")     # 96 / 160: 4.77; one batch on 128 / 128: 4.11
     max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
@@ -296,7 +298,9 @@ def main():
                 reqs.append(Request(pr, pix[off:off + n], np.asarray([g], np.int64), a.max_new_tokens))
                 off += n
             # look-ahead: with EOS disabled and equal caps every slot finishes together, so the whole next group's towers are prefetched
-            outs = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", "0"))).run(reqs)
+            # round 4: the partition launch plan covers any row count, so the look-ahead now wins at 32 occupied slots (4.04 -> 4.26 pages/s
+            # on one GPU, profiles/r04_bench_mixed64*.json) and is the default; DOTS_BENCH_PREFETCH=0 switches it off
+            outs = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots)))).run(reqs)
             out = np.zeros((len(outs), a.max_new_tokens), np.int32)
             out_lens = np.zeros(len(outs), np.int32)
             for i, o in enumerate(outs):
@@ -402,7 +406,7 @@ def main():
         st = eng.stats()                             # device-side HIP-event times of this step (static batches only)
         if deep:                                     # slot mode records no decode events: wall time of this step's decode chunks (host-synchronised),
             st = dict(st)                            # algorithmic bytes by the formula the engine uses for a static batch (weights once per step + KV read)
-            st["decode_ms"] = deep_state["last_decode_ms"]
+            st["decode_ms"] = max(0.0, deep_state["last_decode_ms"] - st["prefill_ms"])      # the chunks queue behind the prefill of the same step
             st["decode_steps"] = half_steps
             st["decode_bytes"] = deep_bytes_per_step
             st["prefill_flops"] = seq_stats["prefill_flops"]
@@ -497,10 +501,10 @@ def main():
                 attn_tflops = lastst["vit_attn_flops"] * n / attn_s / 1e12 if attn_s > 0 else 0.0
                 dec_gbs = lastst["decode_bytes"] * n / dec_s / 1e9 if dec_s > 0 else 0.0
                 vit_tflops = lastst["vit_flops"] * n / vit_s / 1e12 if vit_s > 0 else 0.0
-                r = {"bound": "mfma", "kernel": "flash_attn_kernel<false> (ViT bidirectional var-len attention)",
+                r = {"bound": "mfma", "kernel": "flash_attn64_kernel (ViT bidirectional var-len attention; 4 waves x 64 query rows, round 4)",
                      "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tflops / PEAK_BF16_TFLOPS,
-                     "traffic": recorded("r03_flash_attn_traffic.json", "traffic_bytes_per_launch"),
-                     "traffic_unit": "bytes/launch (PMC on the whole chip, profiles/r03_flash_attn_traffic.json)",
+                     "traffic": recorded("r04_flash_attn_traffic.json", "traffic_bytes_per_launch"),
+                     "traffic_unit": "bytes/launch (PMC on the whole chip, profiles/r04_flash_attn_traffic.json)",
                      "algorithmic_flops_per_launch": lastst["vit_attn_flops"] / max(1, lastst["vit_attn_launches"]),
                      "launches_per_step": lastst["vit_attn_launches"],
                      "avg_launch_ms": ph["vit_attn_ms"] / n / max(1, lastst["vit_attn_launches"])}
@@ -508,8 +512,8 @@ def main():
                 rd = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS,
                       "ms_per_decode_step": ph["decode_ms"] / n / max(1, lastst["decode_steps"]),
                       "algorithmic_bytes_per_decode_step": lastst["decode_bytes"] / max(1, lastst["decode_steps"]),
-                      "traffic": recorded("r03_decode_traffic.json", "traffic_bytes_per_decode_step"),
-                      "traffic_unit": "bytes per decode step (PMC on the whole chip, profiles/r03_decode_traffic.json)"}
+                      "traffic": recorded("r04_decode_traffic.json", "traffic_bytes_per_decode_step"),
+                      "traffic_unit": "bytes per decode step (PMC on the whole chip, B = 8, profiles/r04_decode_traffic.json)"}
                 if cus_vit < 256:
                     for o in (r, rv):
                         o["cus"] = cus_vit

@@ -80,6 +80,8 @@ def main():
     # "continuous_prefetch1/2": the scheduler's look-ahead (the next requests' towers on the CU-masked side stream beside the running slots)
     modes = [("static", run_static), ("continuous", run_continuous), ("continuous_prefetch1", lambda: run_continuous(1)),
              ("continuous_prefetch2", lambda: run_continuous(2))]
+    if a.slots >= 16:                                 # round 4: the partition plan covers any row count, so the look-ahead is measured at larger groups too
+        modes += [("continuous_prefetch4", lambda: run_continuous(4)), ("continuous_prefetch8", lambda: run_continuous(8))]
     for name, fn in modes:
         fn() if a.workload == "tiny" else None                           # tiny: warm the graphs; full size: one cold run each
         eng.synchronize()
