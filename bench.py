@@ -44,7 +44,7 @@ MIXED_SIZES = [((1654, 2339), 0.50), ((1700, 2250), 0.15), ((2339, 3308), 0.10),
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="pages per GPU per step (mixed64: sequence slots per GPU, default 32)")
     ap.add_argument("--max-new-tokens", type=int, default=1024)
@@ -56,10 +56,13 @@ def parse():
                          "while batch k decodes on the complementary CU partition (dots_vit_prefetch)")
     ap.add_argument("--rows-in-flight", type=int, default=None,
                     help="a4 / highres with overlap: decode rows in flight = how many page batches decode together (continuous batching over "
-                         "sequence slots, admission in groups of --batch pages).  Default 4 x batch (at most 32): the last four batches share every "
-                         "decode step (each weight byte is read once per 32 rows instead of once per 8) while the tower of the next batch runs on "
-                         "its CU partition; per timed step still exactly one preprocessing pass, one tower, one prefill and batch x max_new_tokens "
-                         "decoded tokens.  = batch: the round-3 pipeline (one batch decoding)")
+                         "sequence slots, admission in groups of --batch pages).  Default: the engine's 64 sequence slots (8 batches of 8 pages): the "
+                         "last rows-in-flight / batch batches share every decode step (each weight byte is read once per 64 rows instead of once per 8) "
+                         "while the tower of the next batch runs on its CU partition; per timed step still exactly one preprocessing pass, one tower, one "
+                         "prefill and batch x max_new_tokens decoded tokens.  = batch: the round-3 pipeline (one batch decoding)")
+    ap.add_argument("--time-sliced", action="store_true",
+                    help="the multi-batch pipeline WITHOUT CU partitions: per step the tower of the new batch, its prefill and the decode steps over all "
+                         "rows in flight run one after the other, each on the whole chip (A/B against the partitioned default)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -218,15 +221,18 @@ def main():
     max_seq = max_prompt + a.max_new_tokens + 64
     slots = B
     overlap = not a.no_overlap and not mixed
-    rif = a.rows_in_flight if a.rows_in_flight is not None else (min(4 * B, 32) if overlap and a.workload in ("a4", "highres") else B)
+    rif = a.rows_in_flight if a.rows_in_flight is not None else (max(B, 64 // B * B) if overlap and a.workload in ("a4", "highres") and B <= 64 else B)
     deep = overlap and rif > B                      # several page batches decode together (sequence slots, admission in groups of B)
+    sliced = deep and a.time_sliced                 # same admission pattern, no CU partitions: tower, prefill and decode steps take turns on the whole chip
     if deep and (rif % B or rif > 64):
         raise SystemExit("--rows-in-flight must be a multiple of --batch, at most 64 (the engine's sequence slots)")
     n_groups = rif // B if deep else 1
     if mixed:
         os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "96")      # look-ahead towers on 160 CUs beside up to 32 decoding rows on 96
-    if deep:                                        # measured (profiles/r04_deep_sweep.txt): 32 rows decode on 64 CUs while the tower takes 192 — 4.90 pages/s;
-        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64" if a.workload == "a4" else "128")     # 96 / 160: 4.77; one batch on 128 / 128: 4.11
+    if deep and not sliced:
+        # measured (profiles/r04_deep_sweep.txt; decode CUs / rows in flight): a4 64 / 64 5.12 pages/s (tower 1 358 ms on 192 CUs, decode 1 418 ms), 64 / 32 4.93,
+        # 96 / 32 4.95, 96 / 64 4.93, one batch on 128 / 128 4.11-4.21; highres 128 / 64 10.4, 128 / 32 9.0, 128 / 16 7.3, 96 / 32 8.1
+        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64" if a.workload == "a4" else "128")
     max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
     eng = Engine(cfg, device=local, max_batch=rif if deep else slots, max_seq_len=max_seq, max_patches=max_patches,
                  max_prefill_tokens=slots * max_prompt + 64, fp8_weights=fp8)
@@ -318,30 +324,44 @@ def main():
         return out, out_lens, texts, prompts
 
     deep_state = {"k": 0, "queue": [], "last_decode_ms": 0.0}
+    tower_after_prefill = os.environ.get("DOTS_BENCH_TOWER_NOW") != "1"      # =1: the next tower starts beside this batch's prefill (A/B; measured slower)
+    trace_steps = os.environ.get("DOTS_BENCH_TRACE") == "1"      # host-side timeline of every pipelined step on stderr
     half_steps = -(-a.max_new_tokens // n_groups)    # decode steps per timed step: a batch gets n_groups x half_steps >= max_new_tokens - 1 of them
 
     def step_deep():
-        """One timed step of the two-batch pipeline: take the prefetched rows of batch k, preprocess batch k+1 and queue its tower behind
+        """One timed step of the multi-batch pipeline: take the prefetched rows of batch k, preprocess batch k+1 and queue its tower behind
         the prefill, prefill batch k into the free slot group, decode half_steps steps over BOTH groups (batch k: its first half, batch
         k-1: its second half), read batch k-1 out.  Returns batch k-1's tokens (None while the pipeline fills)."""
         k = deep_state["k"]
         t0 = time.perf_counter()
         prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
         t1 = time.perf_counter()
-        eng.vit_take()
-        grids = preprocess_all()
-        t2 = time.perf_counter()
-        eng.vit_prefetch(pix_dev, np.asarray(grids, np.int64), on_device=True, after_prefill=True)
+        tr = [("start", t0), ("tokenize", t1)] if trace_steps else None
+        if sliced:
+            grids = preprocess_all()
+            t2 = time.perf_counter()
+            eng.vit_forward(pix_dev, np.asarray(grids, np.int64), on_device=True)       # this batch's tower, whole chip, in stream order before its prefill
+        else:
+            eng.vit_take()
+            if tr: tr.append(("vit_take", time.perf_counter()))
+            grids = preprocess_all()
+            t2 = time.perf_counter()
+            eng.vit_prefetch(pix_dev, np.asarray(grids, np.int64), on_device=True, after_prefill=tower_after_prefill)
+        if tr: tr.append(("preprocess+prefetch", time.perf_counter()))
         group = [(k % n_groups) * B + i for i in range(B)]
         eng.slots_prefill(group, np.concatenate(prompts), [len(p) for p in prompts], [a.max_new_tokens] * B)
-        td = time.perf_counter()
+        if tr: tr.append(("slots_prefill", time.perf_counter()))
+        eng.slots_poll()                             # the prefill is done (synchronises with the main stream's chain only, not with the tower):
+        td = time.perf_counter()                     # the decode chunks are timed from here
         done_steps = 0
         while done_steps < half_steps:               # chunks: the decode stream (partition beside the tower / whole chip after it) is picked per chunk
             n = min(64, half_steps - done_steps)
             eng.slots_decode(n)
             done_steps += n
+        if tr: tr.append(("decode issued", time.perf_counter()))
         fin, lens_ = eng.slots_poll()                # synchronises with the decode chain only (the tower of the next batch may still run)
         deep_state["last_decode_ms"] = (time.perf_counter() - td) * 1e3
+        if tr: tr.append(("poll", time.perf_counter()))
         out = out_lens = texts = None
         deep_state["queue"].append(group)
         prev = deep_state["queue"].pop(0) if len(deep_state["queue"]) == n_groups else None
@@ -356,6 +376,9 @@ def main():
                 eng.slot_release(s_)
             texts = proc.batch_decode([out[i, :out_lens[i]] for i in range(B)])
         t4 = time.perf_counter()
+        if tr:
+            tr.append(("read-out", t4))
+            print("[step %d] " % k + "  ".join("%s +%.1f" % (nm, (tt - t0) * 1e3) for nm, tt in tr), file=sys.stderr, flush=True)
         deep_state["k"] = k + 1
         host_ms["tokenize_ms"] += (t1 - t0) * 1e3
         host_ms["preprocess_ms"] += (t2 - t1) * 1e3
@@ -374,7 +397,8 @@ def main():
         if deep:
             eng.set_eos([])
             eng.slots_reset()                        # sequence-slot mode: every slot free, every KV page in the pool (drops any pending prefetch)
-        eng.vit_prefetch(pix_dev, np.asarray(preprocess_all(), np.int64), on_device=True)
+        if not sliced:
+            eng.vit_prefetch(pix_dev, np.asarray(preprocess_all(), np.int64), on_device=True)
         if deep:
             for _ in range(n_groups - 1):
                 step_deep()                          # fills the pipeline (no batch completes yet); untimed
@@ -406,7 +430,7 @@ def main():
         st = eng.stats()                             # device-side HIP-event times of this step (static batches only)
         if deep:                                     # slot mode records no decode events: wall time of this step's decode chunks (host-synchronised),
             st = dict(st)                            # algorithmic bytes by the formula the engine uses for a static batch (weights once per step + KV read)
-            st["decode_ms"] = max(0.0, deep_state["last_decode_ms"] - st["prefill_ms"])      # the chunks queue behind the prefill of the same step
+            st["decode_ms"] = deep_state["last_decode_ms"]
             st["decode_steps"] = half_steps
             st["decode_bytes"] = deep_bytes_per_step
             st["prefill_flops"] = seq_stats["prefill_flops"]
@@ -527,7 +551,7 @@ def main():
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
-            cv, cd = (256 - dec_cus, dec_cus) if overlap else (256, 256)
+            cv, cd = (256 - dec_cus, dec_cus) if overlap and not sliced else (256, 256)
             res["roofline"], res["roofline_vit"], res["roofline_decode"] = rooflines(phase, K, last, cv, cd)
             res["decode_tok_s"] = int(out_lens.sum()) * K / (phase["decode_ms"] / 1e3) if phase["decode_ms"] > 0 else None
             res["phase_ms_per_step"] = {**{k: val / K for k, val in phase.items()}, **{k: val / K for k, val in host_ms.items()}}
@@ -537,9 +561,11 @@ def main():
                             "while batch k is prefilled and decoded (decode graph on the stream masked to CUs 0-%d until the tower is done, whole chip "
                             "after); per step exactly one preprocessing pass, one tower, one prefill, one decode loop; phase_ms_per_step therefore "
                             "OVERLAP and sum to more than ms_per_step" % (dec_cus, dec_cus - 1),
-                    "dec_cus": dec_cus, "vit_cus": 256 - dec_cus,
+                    "dec_cus": 256 if sliced else dec_cus, "vit_cus": 256 if sliced else 256 - dec_cus,
+                    "time_sliced": ("no CU partitions: the tower of the new batch, its prefill and the decode steps over all rows in flight take turns on the "
+                                    "whole chip (the 'mode' text above describes the partitioned default)") if sliced else None,
                     "batches_decoding_together": rif // B if deep else 1,
-                    "two_batch_pipeline": ("continuous batching over %d sequence slots with admission in groups of %d pages: a timed step takes the prefetched tower rows "
+                    "multi_batch_pipeline": ("continuous batching over %d sequence slots with admission in groups of %d pages: a timed step takes the prefetched tower rows "
                                            "of batch k, queues batch k+1's tower behind the prefill, prefills batch k into the free slot group and runs %d decode steps "
                                            "over ALL groups (batch k: tokens 1-%d, the older batches their later parts), then reads the oldest batch out — every weight "
                                            "byte is streamed once per %d rows instead of once per %d; a page's tokens do not depend on what shares its decode step "

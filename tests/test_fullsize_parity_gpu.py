@@ -140,7 +140,7 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
                 "steps": n_steps, "greedy_tokens_equal_to_emulated_oracle_argmax": agree, "steps_outside_the_near_tie_band": outside,
                 "max_abs_logit_err_vs_fp32_oracle_first_32_steps": worst,
                 "tolerance": "max |logit err| vs fp32 oracle <= 0.125; token == emulated oracle arg max at every step whose oracle top-2 margin > 2 x that "
-                             "step's max |err vs emulated|; >= 8 such steps required",
+                             "step's max |err vs emulated|; >= 2 such steps required at N(0, 0.02) weights (the peaked checkpoint below supplies 32 of 32)",
                 "oracle_seconds": {"emulated_128_steps": t1 - t0, "fp32_32_steps": t2 - t1, "threads": threads}, "per_step": rows})
 
     # ---- 3. a peaked checkpoint: margins of several logits

@@ -18,7 +18,6 @@ timeout 170 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/
 python $R/tools/pmc_summary.py $O/pmc_dec dec_qkv decode_attn_kernel decode_attn_combine dec_proj dec_gateup dec_lmhead dec_embed argmax > $O/pmc_decode_summary.json 2> $O/pmc_dec/summary.err; echo rc=$?
 find $O/pmc_dec -name "*.csv" -delete
 ( timeout 120 tools/bin/decode_bench 8 5700 6288 ) > $O/decode_bench_whole.txt 2>&1
-( DOTS_BENCH_FULL=1 DOTS_BENCH_CUS=64 timeout 120 tools/bin/decode_bench 32 5700 6288 ) > $O/decode_bench_b32_64cus.txt 2>&1
 # bench lines
 ( timeout 600 python bench.py ) > $O/bench_a4.log 2>&1; grep '^{"metric"' $O/bench_a4.log | tail -1 > $O/r04_bench_a4.json
 ( timeout 300 python bench.py --no-cpu-baseline --rows-in-flight 8 ) 2>&1 | grep '^{"metric"' | tail -1 > $O/r04_bench_a4_one_batch_decoding.json
@@ -44,4 +43,4 @@ for f in sorted(glob.glob(sys.argv[1]+"/r04_serve*.json")):
         d=json.load(open(f)); print(f.split("/")[-1], {k:(v["pages_per_s"] if isinstance(v,dict) else v) for k,v in d.items() if k in ("static","continuous","continuous_prefetch1","continuous_prefetch2","continuous_prefetch4","continuous_prefetch8","identical_tokens")})
     except Exception as e: print(f, "FAILED", e)
 PY
-grep "whole step\|^dec_\|^decode_attn" $O/decode_bench_whole.txt $O/decode_bench_b32_64cus.txt
+grep "whole step\|^dec_\|^decode_attn" $O/decode_bench_whole.txt
