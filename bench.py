@@ -549,6 +549,9 @@ def main():
                     rd["note"] = ("timed region = software-pipelined batches: most decode steps run on the decode partition beside the next batch's vision tower "
                                   "(half-chip launch plan); the step alone on the whole chip is in roofline_decode_sequential")
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
+                    if deep:                       # the PMC traffic figure was taken at 8 rows on the whole chip: it describes roofline_decode_sequential, not this step
+                        rd["traffic"] = None
+                        rd["traffic_unit"] = "not measured for the %d-row step (PMC traffic at B = 8: roofline_decode_sequential.traffic)" % rif
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
             cv, cd = (256 - dec_cus, dec_cus) if overlap and not sliced else (256, 256)
