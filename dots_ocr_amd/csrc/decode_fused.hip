@@ -326,17 +326,22 @@ constexpr int GU_EARLY = GU_EARLY_N;      // k-steps requested before the norm p
 // so the 560 pairs of dots.ocr run as ONE resident round whose leftover pairs are picked up by workgroups that are already there
 // (norm done, streaming) instead of a second dispatch round of cold workgroups.  A group's next weights are requested right after its
 // MFMAs, before the split-K reduction and the SwiGLU epilogue.  Same arithmetic per element.
-template <int MAXR, int NC, typename WT, int PAIRS>
+// TT = batch tiles per workgroup (round 4).  TT = 1: one 16-row tile, as above.  TT = 2 (batches above 16 rows): the X images of TWO tiles sit
+// in LDS (2 x 48 KiB + the reduction buffers = 128 KiB at H = 1536: one workgroup per CU) and every streamed weight fragment feeds one MFMA
+// per tile, so a 64-row batch pulls the 55 MB of W13 through the CUs twice instead of four times.  Per output element the MFMAs, the
+// split-K reduction order and the epilogue are those of TT = 1: bit-identical activations whatever the batch a row sits in.
+template <int MAXR, int NC, typename WT, int PAIRS, int TT = 1>
 __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                                    const WT* __restrict__ Wd, const float* __restrict__ wscale, bf16_t* __restrict__ act,
                                                                    int B, int H, int I, float eps, int XR) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    {   // this workgroup's 16-row batch tile
-        const int t0 = 16 * blockIdx.x;
-        h += (size_t)t0 * H; act += (size_t)t0 * I; B = min(16, B - t0);
+    {   // this workgroup's TT 16-row batch tiles
+        const int t0 = 16 * TT * blockIdx.x;
+        h += (size_t)t0 * H; act += (size_t)t0 * I; B = min(16 * TT, B - t0);
     }
-    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-    f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)XR * H * 2);             // [PAIRS * GU_WAVES][2][64]
+    constexpr int NW = PAIRS * GU_WAVES;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                 // [TT][H/8][XR][8]
+    f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)TT * XR * H * 2);        // [TT][PAIRS * GU_WAVES][2][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int pw = wv / GU_WAVES, kw = wv % GU_WAVES;                             // pair inside the workgroup, K slice
     const int n_pairs = I / 16;
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     const int k0 = kw * KS / GU_WAVES, k1 = (kw + 1) * KS / GU_WAVES;             // k1 - k0 <= GU_G (launcher)
     const bf16x8* xp = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & (XR - 1));
     const int xstride = 4 * XR;
+    const size_t xtile = (size_t)2 * H;                                           // tile 1's image: 16 * H bf16 = 2 H fragments further (TT = 2: XR = 16)
     const int ls = lane_slot<WT>(lane >> 4, lane & 15);
     const int m = lane & 15, g = lane >> 4;
     // wave-uniform chunk bases (scalar registers); the lane's slot `ls` is added per load
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     const WT* wu = up_ptr(pair);
     TRACE(0);
     Rows<MAXR, NC> R;
-    rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, PAIRS * GU_WAVES, lane);
+    rows_issue<MAXR, NC>(R, h, ln_w, B, H, wv, NW, lane);
     // fp8: per-output-channel scales of the packed-W13 rows (G*4 + a)*16 + 4g + r (gate), + 32 (up): small operands, fetched with the rows
     auto scale_g = [&](int pr) { return *reinterpret_cast<const f32x4*>(wscale + ((pr >> 1) * 4 + (pr & 1)) * 16 + 4 * g); };
     auto scale_u = [&](int pr) { return *reinterpret_cast<const f32x4*>(wscale + ((pr >> 1) * 4 + 2 + (pr & 1)) * 16 + 4 * g); };
@@ -372,7 +378,14 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     pin_rows<MAXR, NC>(R);
     if constexpr (is_fp8<WT>::value) { PIN(scg); PIN(scu); }
     TRACE(1);
-    rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, PAIRS * GU_WAVES, lane);
+    if constexpr (TT == 1) rows_norm_to_lds<MAXR, NC>(R, B, H, eps, xs, XR, wv, NW, lane);
+    else {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int r = wv + i * NW;                                 // wave-uniform; row r & 15 of tile r >> 4
+            if (r < B) row_norm_to_lds<NC>(R.v[i], R.w, r & 15, H, eps, xs + (size_t)(r >> 4) * 16 * H, XR, lane);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = GU_EARLY; jj < GU_G; ++jj) {
@@ -384,12 +397,18 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
     for (;;) {
         __syncthreads();                                   // the X image is complete / the reduction buffer of the previous group has been read
         TRACE(3);
-        f32x4 ag = {0, 0, 0, 0}, au = {0, 0, 0, 0};
+        f32x4 ag[TT], au[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { ag[t] = f32x4{0, 0, 0, 0}; au[t] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
         for (int jj = 0; jj < GU_G; ++jj) {
-            const bf16x8 b = xp[(size_t)min(k0 + jj, KS - 1) * xstride];
-            ag = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(a_[jj]), b, ag, 0, 0, 0);
-            au = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_a(u_[jj]), b, au, 0, 0, 0);
+            const bf16x8 wa = as_a(a_[jj]), wb = as_a(u_[jj]);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const bf16x8 b = xp[t * xtile + (size_t)min(k0 + jj, KS - 1) * xstride];
+                ag[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, b, ag[t], 0, 0, 0);
+                au[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, b, au[t], 0, 0, 0);
+            }
         }
         TRACE(4);
         const int cur = pair;
@@ -408,20 +427,31 @@ __global__ __launch_bounds__(PAIRS * GU_WAVES * 64) void dec_gateup_kernel(const
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        red[(wv * 2) * 64 + lane] = ag;
-        red[(wv * 2 + 1) * 64 + lane] = au;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            red[((t * NW + wv) * 2) * 64 + lane] = ag[t];
+            red[((t * NW + wv) * 2 + 1) * 64 + lane] = au[t];
+        }
         __syncthreads();
         TRACE(5);
-        if (kw == 0 && m < B) {
+        if (kw == 0) {
             const int G = cur >> 1, a = cur & 1;
-            f32x4 gs = ag, us = au;
 #pragma unroll
-            for (int ww = 1; ww < GU_WAVES; ++ww) { gs += red[((pw * GU_WAVES + ww) * 2) * 64 + lane]; us += red[((pw * GU_WAVES + ww) * 2 + 1) * 64 + lane]; }
-            if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
-            float o[4];
+            for (int t = 0; t < TT; ++t) {
+                if (m + 16 * t < B) {
+                    f32x4 gs = ag[t], us = au[t];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
-            store_frag4(act, m, G * 32 + a * 16 + 4 * g, XR, o[0], o[1], o[2], o[3]);
+                    for (int ww = 1; ww < GU_WAVES; ++ww) {
+                        gs += red[((t * NW + pw * GU_WAVES + ww) * 2) * 64 + lane];
+                        us += red[((t * NW + pw * GU_WAVES + ww) * 2 + 1) * 64 + lane];
+                    }
+                    if constexpr (is_fp8<WT>::value) { gs *= scg; us *= scu; }
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gs[r] / (1.0f + __expf(-gs[r])) * us[r];
+                    store_frag4(act + (size_t)t * 16 * I, m, G * 32 + a * 16 + 4 * g, XR, o[0], o[1], o[2], o[3]);
+                }
+            }
         }
         TRACE(6);
         if (!more) break;
@@ -490,6 +520,76 @@ __global__ __launch_bounds__(1024) void dec_lmhead_kernel(const bf16_t* __restri
     if constexpr (is_fp8<WT>::value) acc *= sc;
     const int m = lane & 15, g = lane >> 4;
     if (m < B) *reinterpret_cast<f32x4*>(logits + (size_t)m * V + n_tile * 16 + 4 * g) = acc;
+}
+
+// Round 4: batches above 16 rows — TWO 16-row batch tiles per workgroup.  The per-tile kernel above runs one workgroup set per tile,
+// so at 64 rows every lm_head byte crosses a CU's load path four times (once from HBM, three times from L2 / Infinity Cache): 0.27 ms
+// per step at 8 rows on the whole chip became 1 ms on the 64-CU decode partition of the pipelined step.  Here both tiles' X images sit
+// in LDS (2 x 16 x H x 2 B = 96 KiB at H = 1536: one workgroup per CU) and every streamed weight fragment feeds one MFMA per tile.
+// Same MFMAs in the same order per output element as the per-tile kernel (even / odd k-steps on two accumulators, added at the end):
+// bit-identical logits, so a sequence's tokens still do not depend on the batch it shares.
+template <int NC, typename WT>
+__global__ __launch_bounds__(1024) void dec_lmhead2_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
+                                                           const WT* __restrict__ Wd, const float* __restrict__ wscale, float* __restrict__ logits,
+                                                           int B, int H, int V, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XR = 16;
+    {   // this workgroup's pair of 16-row batch tiles
+        const int t0 = 32 * blockIdx.x;
+        h += (size_t)t0 * H; logits += (size_t)t0 * V; B = min(32, B - t0);
+    }
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                      // [2][H/8][16][8]
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int n_tile = min((int)blockIdx.y * 16 + wv, V / 16 - 1);
+    const int KS = H / 32;
+    constexpr int LM_G = LmG<WT>::value;
+    const WT* wp = Wd + ((size_t)n_tile * KS) * 64 + lane_slot<WT>(lane >> 4, lane & 15);
+    Rows<2, NC> R;                                                     // rows wv and wv + 16: row wv of either tile
+    rows_issue<2, NC>(R, h, ln_w, B, H, wv, 16, lane);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + n_tile * 16 + 4 * (lane >> 4));
+    __builtin_amdgcn_sched_barrier(0);
+    WT a[LM_G];
+    weights_issue<LM_G>(a, wp, 0, KS, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    pin_rows<2, NC>(R);
+    if constexpr (is_fp8<WT>::value) PIN(sc);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (wv + 16 * t < B) row_norm_to_lds<NC>(R.v[t], R.w, wv, H, eps, xs + (size_t)t * 16 * H, XR, lane);
+    __syncthreads();
+    const bf16x8* xp0 = reinterpret_cast<const bf16x8*>(xs) + (lane >> 4) * XR + (lane & 15);
+    const bf16x8* xp1 = xp0 + (size_t)2 * H;                           // tile 1: 16 * H bf16 = 2 H fragments further
+    const int xstride = 4 * XR;
+    f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    int ks = 0;
+    for (; ks + LM_G < KS; ks += LM_G) {
+        WT an[LM_G];
+        weights_issue<LM_G>(an, wp, ks + LM_G, KS, lane);
+#pragma unroll
+        for (int jj = 0; jj < LM_G; jj += 2) {
+            const bf16x8 w0 = as_a(a[jj]), w1 = as_a(a[jj + 1]);
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xp0[(size_t)(ks + jj) * xstride], acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xp1[(size_t)(ks + jj) * xstride], acc10, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xp0[(size_t)(ks + jj + 1) * xstride], acc01, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xp1[(size_t)(ks + jj + 1) * xstride], acc11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < LM_G; ++jj) a[jj] = an[jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < LM_G; jj += 2) {
+        const bf16x8 w0 = as_a(a[jj]), w1 = as_a(a[jj + 1]);
+        acc00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xp0[(size_t)(ks + jj) * xstride], acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xp1[(size_t)(ks + jj) * xstride], acc10, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xp0[(size_t)(ks + jj + 1) * xstride], acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xp1[(size_t)(ks + jj + 1) * xstride], acc11, 0, 0, 0);
+    }
+    f32x4 acc0 = acc00 + acc01, acc1 = acc10 + acc11;
+    if constexpr (is_fp8<WT>::value) { acc0 *= sc; acc1 *= sc; }
+    const int m = lane & 15, g = lane >> 4;
+    if (m < B) *reinterpret_cast<f32x4*>(logits + (size_t)m * V + n_tile * 16 + 4 * g) = acc0;
+    if (m + 16 < B) *reinterpret_cast<f32x4*>(logits + (size_t)(m + 16) * V + n_tile * 16 + 4 * g) = acc1;
 }
 
 // Dynamic-LDS opt-in above 64 KiB, once per (kernel, device): handles of different devices may live in one process.
@@ -598,6 +698,23 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     // at B <= 8 one pair per workgroup is faster (13.3 vs 13.9 us at B = 8, 11.9 vs 13.6 at B = 1).  DOTS_OCR_GATEUP_PAIRS=1/2 forces either.
     static const int pairs_env = [] { const char* e = getenv("DOTS_OCR_GATEUP_PAIRS"); return e ? atoi(e) : 0; }();
     const int pairs = pairs_env ? pairs_env : (B > 8 ? 2 : 1);
+    static const bool per_tile = getenv("DOTS_OCR_GATEUP_PER_TILE") != nullptr;     // A/B switch: one workgroup set per 16-row tile at every batch size
+    if (B > 16 && !per_tile && (I / 16) % 2 == 0) {          // two batch tiles per workgroup (TT = 2): every weight byte feeds 32 rows
+        static uint32_t attr_t = 0;
+        static int occ_t = 0;
+        const size_t lds_t = (size_t)2 * 16 * H * 2 + 2 * 4 * GU_WAVES * 64 * sizeof(f32x4);
+        if (lds_t <= 160 * 1024) {
+            auto kern_t = dec_gateup_kernel<4, NC_MAX, WT, 2, 2>;
+            hipError_t et = ensure_lds(kern_t, lds_t, &attr_t);
+            if (et != hipSuccess) return et;
+            const int tiles2 = (B + 31) / 32;
+            int gy = I / 32;
+            const int cap = cap_env > 0 ? cap_env : (part_cus > 0 ? part_cus * resident_blocks_per_cu(kern_t, 2 * GU_WAVES * 64, lds_t, &occ_t) : 0);
+            if (cap > 0) gy = std::max(1, std::min(gy, cap / tiles2));
+            hipLaunchKernelGGL(kern_t, dim3(tiles2, gy), dim3(2 * GU_WAVES * 64), lds_t, s, h, ln_w, W13d, wscale, act, B, H, I, eps, 16);
+            return hipGetLastError();
+        }
+    }
     if (pairs == 2 && (I / 16) % 2 == 0) {
         static uint32_t attr2[2] = {0, 0};
         static int occ2[2] = {0, 0};
@@ -635,7 +752,14 @@ template <typename WT>
 static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const WT* Wd, const float* wscale, float* logits,
                                 int B, int H, int V, float eps) {
     if (H % (32 * LmG<WT>::value)) return hipErrorInvalidValue;
-    static uint32_t attr = 0;
+    static uint32_t attr = 0, attr2 = 0;
+    static const bool per_tile = getenv("DOTS_OCR_LMHEAD_PER_TILE") != nullptr;       // A/B switch: one workgroup set per 16-row tile at every batch size
+    if (B > 16 && !per_tile && (size_t)32 * H * 2 <= 160 * 1024) {                   // two batch tiles per workgroup: each weight byte feeds 32 rows
+        hipError_t e2 = ensure_lds(dec_lmhead2_kernel<NC_MAX, WT>, (size_t)32 * H * 2, &attr2);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL((dec_lmhead2_kernel<NC_MAX, WT>), dim3((B + 31) / 32, (V / 16 + 15) / 16), dim3(1024), (size_t)32 * H * 2, s, h, ln_w, Wd, wscale, logits, B, H, V, eps);
+        return hipGetLastError();
+    }
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2;
     hipError_t e = ensure_lds(dec_lmhead_kernel<NC_MAX, WT>, (size_t)16 * H * 2, &attr);
