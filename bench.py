@@ -230,8 +230,8 @@ def main():
     if mixed:
         os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "96")      # look-ahead towers on 160 CUs beside up to 32 decoding rows on 96
     if deep and not sliced:
-        # measured (profiles/r04_deep_sweep.txt; decode CUs / rows in flight): a4 64 / 64 5.12 pages/s (tower 1 358 ms on 192 CUs, decode 1 418 ms), 64 / 32 4.93,
-        # 96 / 32 4.95, 96 / 64 4.93, one batch on 128 / 128 4.11-4.21; highres 128 / 64 10.4, 128 / 32 9.0, 128 / 16 7.3, 96 / 32 8.1
+        # measured (profiles/r04_deep_sweep.txt; decode CUs / rows in flight): a4 64 / 64 5.12 pages/s (tower 1 358 ms on 192 CUs, decode 1 418 ms; 5.34-5.43 with two batch tiles per workgroup in gate|up / lm_head: decode 1 270 ms), 64 / 32 4.93,
+        # 96 / 32 4.95, 96 / 64 4.93, one batch on 128 / 128 4.11-4.21; highres 128 / 64 10.4 (11.5 with the two-tile kernels), 128 / 32 9.0, 128 / 16 7.3, 96 / 32 8.1
         os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64" if a.workload == "a4" else "128")
     max_patches = max(sum(sorted(n_patches, reverse=True)[:slots]), max(n_patches)) + 64
     eng = Engine(cfg, device=local, max_batch=rif if deep else slots, max_seq_len=max_seq, max_patches=max_patches,
