@@ -152,6 +152,29 @@ def test_continuous_worker_keeps_slots_full_and_separates_sampling_parameters():
         assert d["choices"][0]["finish_reason"] == "length" and d["usage"]["completion_tokens"] == 3
 
 
+def test_continuous_worker_look_ahead_default_and_override():
+    """Round 4: the scheduler look-ahead is on by default in the server (2 requests up to 8 slots, min(8, slots / 2) above; measured in
+    tools/serve_bench.py), `--look-ahead 0` / look_ahead=0 switches it off, and an engine without vit_prefetch silently runs without it."""
+    from dots_ocr_amd.scheduler import ContinuousBatcher
+    from dots_ocr_amd.server import ContinuousWorker
+    cfg = DotsConfig.tiny()
+    proc = DotsOcrProcessor(cfg)
+    model = _SlotModel(proc, cfg)
+    for slots, want in ((3, 2), (8, 2), (16, 8), (32, 8), (12, 6)):
+        w = ContinuousWorker(model, proc, max_batch=slots)
+        try:
+            assert w.look_ahead == want
+        finally:
+            w.close()
+    w = ContinuousWorker(model, proc, max_batch=8, look_ahead=0)
+    try:
+        assert w.look_ahead == 0
+    finally:
+        w.close()
+    cb = ContinuousBatcher(model.engine, eos_ids=(), prefetch=4)
+    assert cb.prefetch == (4 if hasattr(model.engine, "vit_prefetch") else 0)
+
+
 def test_server_refuses_remote_and_local_image_locations_by_default(tmp_path):
     """a client-supplied image_url must not make the server read local files or fetch URLs (SSRF) unless the
     operator opted in; data: URLs (all the reference client sends, model/inference.py:20-33) always work."""
