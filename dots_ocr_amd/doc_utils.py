@@ -19,6 +19,10 @@ from typing import Dict, List, Optional
 from PIL import Image
 
 
+MAX_STREAM_BYTES = 512 << 20        # decoded size cap of one stream (an A4 page at 600 dpi RGB is 104 MB)
+MAX_PAGES = 100_000
+
+
 class PdfContentNotSupported(NotImplementedError):
     """The built-in rasteriser only renders image-only (scanned) pages; install PyMuPDF for text / vector pages."""
 
@@ -277,7 +281,9 @@ class PdfDocument:
         for num, val in list(self.objs.items()):          # object streams (PDF 1.5)
             if isinstance(val, dict) and val.get("Type") == "ObjStm":
                 body = self.stream(num)
-                n, first = self.get(val["N"]), self.get(val["First"])
+                n, first = self.get(val.get("N")), self.get(val.get("First"))
+                if not (isinstance(n, int) and isinstance(first, int) and 0 <= first <= len(body) and 0 <= n <= first):
+                    raise ValueError("malformed PDF object stream header")        # every (number, offset) pair takes >= 1 byte of the header
                 head = _Lexer(body[:first])
                 pairs = [(head.token(), head.token()) for _ in range(n)]
                 for onum, off in pairs:
@@ -311,7 +317,10 @@ class PdfDocument:
         for f, pr in zip(filters, parms):
             f, pr = self.get(f), self.get(pr) or {}
             if f in ("FlateDecode", "Fl"):
-                raw = zlib.decompressobj().decompress(raw)
+                dec = zlib.decompressobj()
+                raw = dec.decompress(raw, MAX_STREAM_BYTES)          # bounded: a few KB of input must not become gigabytes
+                if dec.unconsumed_tail:
+                    raise ValueError(f"PDF stream inflates beyond {MAX_STREAM_BYTES >> 20} MiB")
                 if self.get(pr.get("Predictor", 1)) >= 10:
                     raw = _png_unpredict(raw, self.get(pr.get("Columns", 1)), self.get(pr.get("Colors", 1)), self.get(pr.get("BitsPerComponent", 8)))
                 elif self.get(pr.get("Predictor", 1)) == 2:
@@ -327,16 +336,20 @@ class PdfDocument:
                 raise PdfContentNotSupported(f"stream filter {f}")
         return raw
 
-    def _walk(self, node, inherited):
+    def _walk(self, node, inherited, _seen=None, _depth=0):
         if not isinstance(node, dict):
             return
+        _seen = set() if _seen is None else _seen
+        if id(node) in _seen or _depth > 64 or len(self.pages) >= MAX_PAGES:      # /Kids cycles, absurd nesting, page bombs
+            raise ValueError("malformed PDF page tree (cycle, depth > 64 or too many pages)")
+        _seen.add(id(node))
         inh = dict(inherited)
         for k in ("MediaBox", "CropBox", "Resources", "Rotate"):
             if k in node:
                 inh[k] = node[k]
         if node.get("Type") == "Pages" or "Kids" in node:
             for kid in self.get(node.get("Kids")) or []:
-                self._walk(self.get(kid), inh)
+                self._walk(self.get(kid), inh, _seen, _depth + 1)
         else:
             self.pages.append(_Page(self, node, inh))
 
@@ -481,6 +494,8 @@ class _Page:
             px0, px1 = (ux0 - self.x0) * z, (ux1 - self.x0) * z
             py0, py1 = (self.height - (uy1 - self.y0)) * z, (self.height - (uy0 - self.y0)) * z
             bw, bh = max(1, round(px1 - px0)), max(1, round(py1 - py0))
+            if bw > 4 * W or bh > 4 * H:                       # a placement far larger than the page raster: refuse instead of allocating it
+                raise ValueError(f"PDF image placement {bw}x{bh} px exceeds the page raster {W}x{H}")
             if a < 0:
                 im = im.transpose(Image.FLIP_LEFT_RIGHT)
             if d < 0:

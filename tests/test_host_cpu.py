@@ -622,6 +622,62 @@ def test_continuous_batcher_look_ahead_prefetches_the_next_towers_with_a_fake_en
     assert not any(e[0] in ("prefetch", "take") for e in eng.log)
 
 
+def test_pdf_reader_resource_limits_on_untrusted_files(monkeypatch):
+    """the built-in PDF reader bounds what a hostile file can make it allocate or recurse into: a Flate bomb, a /Kids cycle,
+    an object stream with a lying header and an image placed far larger than the page all fail with ValueError."""
+    import zlib
+    from dots_ocr_amd import doc_utils as du
+
+    def build(objs):
+        out, offs = bytearray(b"%PDF-1.5\n"), {}
+        for num, (dic, stream) in objs.items():
+            offs[num] = len(out)
+            out += b"%d 0 obj\n" % num + dic
+            if stream is not None:
+                out += b"\nstream\n" + stream + b"\nendstream"
+            out += b"\nendobj\n"
+        out += b"trailer\n<< /Root 1 0 R /Size %d >>\n%%%%EOF\n" % (max(objs) + 1)
+        return bytes(out)
+
+    # 1. decompression bomb: 64 MiB of zeros in ~64 KiB, cap lowered to 1 MiB for the test
+    monkeypatch.setattr(du, "MAX_STREAM_BYTES", 1 << 20)
+    bomb = zlib.compress(b"\0" * (64 << 20), 9)
+    content = b"q 100 0 0 100 0 0 cm /Im0 Do Q"
+    objs = {1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+            2: (b"<< /Type /Pages /Kids [3 0 R] /Count 1 /MediaBox [0 0 100 100] >>", None),
+            3: (b"<< /Type /Page /Parent 2 0 R /Resources << /XObject << /Im0 4 0 R >> >> /Contents 5 0 R >>", None),
+            4: (b"<< /Type /XObject /Subtype /Image /Width 8192 /Height 8192 /ColorSpace /DeviceGray /BitsPerComponent 8 /Filter /FlateDecode "
+                b"/Length %d >>" % len(bomb), bomb),
+            5: (b"<< /Length %d >>" % len(content), content)}
+    with pytest.raises(ValueError, match="inflates beyond"):
+        du.PdfDocument(build(objs))[0].render(72)
+    # 2. a page tree that contains itself
+    cyc = {1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+           2: (b"<< /Type /Pages /Kids [3 0 R] /Count 1 /MediaBox [0 0 100 100] >>", None),
+           3: (b"<< /Type /Pages /Kids [2 0 R] /Count 1 >>", None)}
+    with pytest.raises(ValueError, match="page tree"):
+        du.PdfDocument(build(cyc))
+    # 3. object stream whose header claims more objects than it has bytes for
+    body = zlib.compress(b"7 0 << /Type /Catalog >>")
+    bad = {1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+           2: (b"<< /Type /Pages /Kids [] /Count 0 >>", None),
+           6: (b"<< /Type /ObjStm /N 100000000 /First 4 /Filter /FlateDecode /Length %d >>" % len(body), body)}
+    with pytest.raises(ValueError, match="object stream"):
+        du.PdfDocument(build(bad))
+    # 4. an image placed 100x larger than its page
+    monkeypatch.setattr(du, "MAX_STREAM_BYTES", 512 << 20)
+    px = zlib.compress(bytes(16 * 16))
+    big = b"q 10000 0 0 10000 0 0 cm /Im0 Do Q"
+    huge = {1: (b"<< /Type /Catalog /Pages 2 0 R >>", None),
+            2: (b"<< /Type /Pages /Kids [3 0 R] /Count 1 /MediaBox [0 0 100 100] >>", None),
+            3: (b"<< /Type /Page /Parent 2 0 R /Resources << /XObject << /Im0 4 0 R >> >> /Contents 5 0 R >>", None),
+            4: (b"<< /Type /XObject /Subtype /Image /Width 16 /Height 16 /ColorSpace /DeviceGray /BitsPerComponent 8 /Filter /FlateDecode "
+                b"/Length %d >>" % len(px), px),
+            5: (b"<< /Length %d >>" % len(big), big)}
+    with pytest.raises(ValueError, match="exceeds the page raster"):
+        du.PdfDocument(build(huge))[0].render(72)
+
+
 def test_pdf_rasteriser_colour_modes_rotation_and_several_images_per_page():
     """What scanners really produce: gray / RGB / CMYK JPEG, bilevel Group-4 fax (CCITTFaxDecode), palette images; a /Rotate 90 page;
     a page assembled from two image strips."""
