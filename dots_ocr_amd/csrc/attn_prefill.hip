@@ -382,6 +382,17 @@ constexpr int RING_BYTES = RING * 2 * KT_BYTES;               // KT_BYTES == VT_
 #define F64_EXP_C "v_exp_f32_e32 %[u1], %[u1]\n\tv_add_f32_e32 %[ps], %[ps], %[u0]\n\tv_add_f32_e32 %[ps], %[ps], %[u1]\n\tv_cvt_pk_bf16_f32 %[wy], %[u0], %[u1]"
 #endif
 
+// -DF64_PK (EXPERIMENTAL, not in the default build, not yet run on a GPU): the packed-fp32 form of the exp stream.  The two scores of a
+// pair are scaled and shifted by ONE v_pk_fma_f32 (the running maxima of the two query blocks share one register pair, picked by
+// op_sel; the scale is a scalar pair), so three gaps carry 12 filler instructions instead of 14 — exactly the 4 free issue slots per
+// MFMA that tools/mfma_filler_probe.hip measured.  Same fused multiply-adds, same results.  Inline asm has no sub-register syntax, so the
+// two pairs in flight live in FIXED registers whose halves the strings name: t = v[252:253], u = v[254:255].
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define F64_PKFMA(dst, src, ms) "v_pk_fma_f32 " dst ", " src ", %[sc], %[m] op_sel:[0,0," ms "] op_sel_hi:[1,1," ms "] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+#define F64_PK_A(ms) F64_PKFMA("v[252:253]", "%[x]", ms) F64_PKFMA("v[254:255]", "%[y]", ms) "v_exp_f32_e32 v252, v252\n\tv_exp_f32_e32 v253, v253"
+#define F64_PK_B "v_exp_f32_e32 v254, v254\n\tv_exp_f32_e32 v255, v255\n\tv_add_f32_e32 %[ps], %[ps], v252\n\tv_add_f32_e32 %[ps], %[ps], v253"
+#define F64_PK_C "v_cvt_pk_bf16_f32 %[wx], v252, v253\n\tv_add_f32_e32 %[ps], %[ps], v254\n\tv_add_f32_e32 %[ps], %[ps], v255\n\tv_cvt_pk_bf16_f32 %[wy], v254, v255"
+
 // compile-time loop: the gap index must be a constant expression (operand selection by `if constexpr`, never by run-time selects)
 template <int... I, class F> DEVI void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEVI void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
@@ -547,7 +558,13 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         float ps[2] = {0.f, 0.f};
         uint32_t pw[2][4][4];                                     // P(j): [block][key slab][word]
         float t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;             // the two pairs in flight
-        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &frag, &dma_k, &dma_v, kl, vl, j, lds0, k_lane, scale_log2e](auto gc) {
+#ifdef F64_PK
+        f32x2 t2 = {0.f, 0.f}, u2 = {0.f, 0.f};                   // ... as register pairs (fixed: v[252:253], v[254:255])
+        const f32x2 m2 = {m_run[0], m_run[1]}, sc2 = {scale_log2e, scale_log2e};
+#else
+        const float t2 = 0.f, u2 = 0.f, m2 = 0.f, sc2 = 0.f;     // (unused; keeps the capture list below the same in both builds)
+#endif
+        static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &t2, &u2, &m2, &sc2, &frag, &dma_k, &dma_v, kl, vl, j, lds0, k_lane, scale_log2e](auto gc) {
             constexpr int g = decltype(gc)::value + 8;
             if constexpr (g == 32) {
                 if (need) {                                       // wave-uniform
@@ -605,6 +622,40 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                 // scores of pair (block b, slab s, word e): S[b][s >> 1][8 (s & 1) + 2 e], + 1
                 const float xs0 = sc[xb][xsl >> 1][8 * (xsl & 1) + 2 * xe], xs1 = sc[xb][xsl >> 1][8 * (xsl & 1) + 2 * xe + 1];
                 const float ys0 = sc[yb][ysl >> 1][8 * (ysl & 1) + 2 * ye], ys1 = sc[yb][ysl >> 1][8 * (ysl & 1) + 2 * ye + 1];
+#ifdef F64_PK
+                static_assert(xb == yb && xsl == ysl, "the two pairs of a triple belong to one block and one key slab");
+                const f32x2 xp = {xs0, xs1}, yp = {ys0, ys1};                               // adjacent, even-aligned score registers
+                if constexpr (is_qk) {
+                    if constexpr (ph == 0) {
+                        if constexpr (xb == 0)
+                            asm volatile(F64_MFMA_S F64_PK_A("0") : [d] "+v"(sn[bk][hf]), "={v[252:253]}"(t2), "={v[254:255]}"(u2)
+                                         : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [x] "v"(xp), [y] "v"(yp), [sc] "s"(sc2), [m] "v"(m2));
+                        else
+                            asm volatile(F64_MFMA_S F64_PK_A("1") : [d] "+v"(sn[bk][hf]), "={v[252:253]}"(t2), "={v[254:255]}"(u2)
+                                         : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [x] "v"(xp), [y] "v"(yp), [sc] "s"(sc2), [m] "v"(m2));
+                    } else if constexpr (ph == 1)
+                        asm volatile(F64_MFMA_S F64_PK_B : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), "+{v[254:255]}"(u2)
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), "{v[252:253]}"(t2));
+                    else
+                        asm volatile(F64_MFMA_S F64_PK_C : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [wy] "=&v"(pw[yb][ysl][ye])
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), "{v[252:253]}"(t2), "{v[254:255]}"(u2));
+                } else {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
+                    if constexpr (ph == 0) {
+                        if constexpr (xb == 0)
+                            asm volatile(F64_MFMA_S F64_PK_A("0") : [d] "+a"(o[bk][dt]), "={v[252:253]}"(t2), "={v[254:255]}"(u2)
+                                         : [a] "v"(fa[cur][hf]), [b] "v"(pf), [x] "v"(xp), [y] "v"(yp), [sc] "s"(sc2), [m] "v"(m2));
+                        else
+                            asm volatile(F64_MFMA_S F64_PK_A("1") : [d] "+a"(o[bk][dt]), "={v[252:253]}"(t2), "={v[254:255]}"(u2)
+                                         : [a] "v"(fa[cur][hf]), [b] "v"(pf), [x] "v"(xp), [y] "v"(yp), [sc] "s"(sc2), [m] "v"(m2));
+                    } else if constexpr (ph == 1)
+                        asm volatile(F64_MFMA_S F64_PK_B : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), "+{v[254:255]}"(u2)
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), "{v[252:253]}"(t2));
+                    else
+                        asm volatile(F64_MFMA_S F64_PK_C : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[xb]), [wx] "=&v"(pw[xb][xsl][xe]), [wy] "=&v"(pw[yb][ysl][ye])
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), "{v[252:253]}"(t2), "{v[254:255]}"(u2));
+                }
+#else
                 if constexpr (is_qk) {
                     if constexpr (ph == 0)
                         asm volatile(F64_MFMA_S F64_EXP_A : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[xb]), [t0] "=&v"(t0), [t1] "=&v"(t1)
@@ -627,6 +678,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                         asm volatile(F64_MFMA_S F64_EXP_C : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
                                      : [a] "v"(fa[cur][hf]), [b] "v"(pf), [u0] "v"(u0));
                 }
+#endif
             }
         });
         F64_STAMP(3);                                             // gaps 8-63
