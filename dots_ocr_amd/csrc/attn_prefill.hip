@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
 #endif
         static_for<56>([&sn, &sc, &qf, &fa, &o, &pw, &ps, &m_run, &m_old, &l_run, &need, &t0, &t1, &u0, &u1, &t2, &u2, &m2, &sc2, &frag, &dma_k, &dma_v, kl, vl, j, lds0, k_lane, scale_log2e](auto gc) {
             constexpr int g = decltype(gc)::value + 8;
+            (void)t2; (void)u2; (void)m2; (void)sc2;                                        // used by the -DF64_PK build only
             if constexpr (g == 32) {
                 if (need) {                                       // wave-uniform
 #pragma unroll
