@@ -1606,6 +1606,13 @@ int dots_set_decode_plan(DotsEngine* e, int plan) {
     return DOTS_OK;
 }
 
+int dots_set_gemm_plan(DotsEngine* e, int plan) {
+    if (!e) return DOTS_E_INVALID;
+    if (plan < 0 || plan > 1) return e->fail(DOTS_E_INVALID, "gemm plan must be 0 (8-wave ping-pong) or 1 (one wave per SIMD)");
+    gemm_set_plan(plan);
+    return DOTS_OK;
+}
+
 int dots_get_logits(DotsEngine* e, float* out) {
     if (!e || !out) return DOTS_E_INVALID;
     if (e->B < 1) return e->fail(DOTS_E_STATE, "no prefilled batch");

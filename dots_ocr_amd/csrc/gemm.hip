@@ -20,6 +20,7 @@
 // Requirements (checked by the launcher): N % 128 == 0, K % 64 == 0, 16-B aligned rows.  M is free
 // (rows are clamped on load, masked on store).
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -38,11 +39,11 @@ DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---- epilogue shared by both tile shapes: lane owns (m, 4 consecutive n) per (fn, fm, rq) of its 64x64 wave tile.
 // nw0 = first weight row (n) of the wave tile, mw0 = first activation row (m) of the wave tile.
-template <int EPI, int FN>
-DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
+template <int EPI, int FN, int FM = 2>
+DEVI void gemm_epilogue(const f32x16 (&acc)[FN][FM], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
                         void* Cout, int M, int ldc, int nw0, int mw0, int l31, int hi, const float* __restrict__ rowscale = nullptr) {
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
+    for (int fm = 0; fm < FM; ++fm) {
         const int m = mw0 + fm * 32 + l31;
         if (m >= M) continue;
         const float rs = rowscale ? rowscale[m] : 1.f;           // fp8 activations: per-token scale (quant.hip)
@@ -111,8 +112,8 @@ DEVI void gemm_epilogue(const f32x16 (&acc)[FN][2], const bf16_t* __restrict__ b
 // LDS image [32 rows][32 slots of 16 B], slot ^= (row & 15) << 1: conflict-free ds_write_b128 (8 consecutive rows per group),
 // and the slot pair (2k, 2k + 1) of a lane's 8 floats stays adjacent.  Private to the wave: no barrier, LDS ops of one wave are
 // executed in order.
-template <int EPI>
-DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][2], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
+template <int EPI, int FM = 2>
+DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][FM], const bf16_t* __restrict__ bias, const float* __restrict__ colscale, const bf16_t* R,
                             bf16_t* __restrict__ C, int M, int ldc, int nw0, int mw0, int l, char* stage, const float* __restrict__ rowscale = nullptr) {
     const int hi = l >> 5, l31 = l & 31;
     constexpr bool SW = EPI == EPI_SWIGLU;
@@ -128,7 +129,7 @@ DEVI void gemm_epilogue_lds(const f32x16 (&acc)[4][2], const bf16_t* __restrict_
         bi1[e] = (SW && bias) ? bf2f(bias[nw0 + gcol + 32 + e]) : 0.f;
     }
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
+    for (int fm = 0; fm < FM; ++fm) {
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
@@ -516,6 +517,176 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: ONE wave per SIMD (the structure of flash_attn64_kernel applied to the GEMM).  256(n) x 256(m) tile, 4 waves as
+// 2(n) x 2(m), wave tile 128 x 128 = 4 x 4 accumulators of 32 x 32 in 256 AGPRs; every operand fragment now feeds FOUR MFMAs
+// (the 8-wave kernels: two), so a K step of 16 costs 8 ds_read_b128 per 16 MFMAs per wave and the LDS pipe is a quarter busy.
+// What the ping-pong kernel loses (profiles/r02_pmc_gemm.json: MFMA pipe 58 % busy; waves parked 26 %, issue-stalled 50 %) is
+// two barriers per 16 MFMAs per wave group and a global->LDS path run in HALF cache lines (its sub-tile rows are 64 B: every
+// 128-B line of an operand is requested twice, a kilobyte of DMA per 24-32 cycles measured).  Here:
+//   * K tiles of 64: an operand row in LDS is one whole 128-B line, a DMA piece (buffer_load ... lds, 1 KiB per
+//     wave-instruction) is 8 full lines; LDS image [256 rows][128 B], 16-B slot XOR (row >> 1) & 7 on the source side and on
+//     the read (the lock-step kernel's image: conflict-free ds_read_b128);
+//   * a ring of FIVE 32-KB units (= all 160 KB of LDS), unit 2t = W rows of K tile t, unit 2t + 1 = X rows: while tile t is
+//     multiplied, tile t + 1 is resident, W(t + 2) is in flight, and the two units of tile t are re-filled (X(t + 2), W(t + 3))
+//     as soon as every wave holds its last fragments of tile t — ONE barrier per 64 MFMAs, placed in front of the tile's last
+//     K step (16 MFMAs), so the requests have 1.5-2.5 tile periods (3-5 k cycles) to land;
+//   * the tile body is 64 `asm volatile` MFMA statements (compile-time fragment / accumulator selection); between them, in
+//     program order, the 32 fragment reads of the next K step (one per gap, first half of each step), the 16 DMA pieces and the
+//     barrier: ~1.5 issue slots per gap against the 4 that are free behind a 32x32x16 MFMA (profiles/r04_mfma_filler_probe.txt);
+//   * the last two K tiles run copies of the body that request nothing (MODE 1: waits for everything; MODE 2: no barrier), so
+//     the steady-state body carries no branches and no request ever leaves the operands' bounds.
+// Timing ablations (never in the product build; tools/build_variant_gemm.sh): -DW4_NO_DMA requests nothing after the prologue,
+// -DW4_NO_STORE drops the epilogue (results are then garbage).
+// Ordering (RAW): a wave waits for its own pieces of tile t + 1 (vmcnt(8) leaves the 8 W(t + 2) pieces of this tile's head in
+// flight) before the barrier of tile t; fragments of tile t + 1 are read behind that barrier.  (WAR): the units of tile t are
+// re-filled behind the same barrier, which every wave passes only with all its reads of tile t returned (lgkmcnt(0)).
+constexpr int W4_UNIT = 256 * 128, W4_RING = 5;
+
+template <int... I, class F> DEVI void gemm_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> DEVI void gemm_static_for(F&& f) { gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = l >> 5, l31 = l & 31;
+
+    int bid = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int per_group = group_m * n_tiles;
+    const int g = bid / per_group;
+    const int first_m = g * group_m;
+    const int gsz = min(m_tiles - first_m, group_m);
+    const int in_grp = bid - g * per_group;
+    const int tm = first_m + in_grp % gsz;
+    const int tn = in_grp / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // ---- LDS-DMA: piece p (0-31 per unit) = rows 8p .. 8p+7 x 128 B; wave w copies pieces w + 4i (i < 8): rows advance by 32 per i,
+    // which leaves the swizzle term (row >> 1) & 7 unchanged -> one per-lane source offset for W (the row step enters through the
+    // scalar offset); the X rows are clamped to M - 1 per piece (8 per-lane offsets), so no request leaves the matrix
+    const int prow = 8 * w + (l >> 3);
+    const int chunk = ((l & 7) ^ ((4 * w + (l >> 4)) & 7)) << 4;
+    const int w_src = prow * (K * 2) + chunk;
+    int x_src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x_src[i] = (min(m0 + prow + 32 * i, M - 1) - m0) * (lda * 2) + chunk;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * K), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, 0x7ffffff0, 0x00020000);
+    const int w_step = 32 * K * 2;                               // bytes between W rows 32 apart
+    auto dma_w = [&](int t, int slot, int i) {                   // piece i of W(t) -> ring slot
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem2 + slot * W4_UNIT + (w + 4 * i) * 1024), 16, w_src,
+                                                 t * 128 + i * w_step, 0, 0);
+    };
+    auto dma_x = [&](int t, int slot, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem2 + slot * W4_UNIT + (w + 4 * i) * 1024), 16, x_src[i],
+                                                 t * 128, 0, 0);
+    };
+
+    const int wn = w >> 1, wm = w & 1;                           // 2 x 2 waves
+    // fragment gather: row r, K step ks -> slot ((2 ks + hi) ^ ((r >> 1) & 7)) << 4 = lane constant ^ (ks << 5); r = wave base + 32 f + l31
+    const int rsw = (l31 >> 1) & 7;
+    const int lane_sw = ((hi ^ (rsw & 1)) << 4) | ((rsw >> 1) << 5);
+    const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem2;     // dynamic segment: the kernel has no static LDS
+    const int a_lane = lds0 + (wn * 128 + l31) * 128 + lane_sw;
+    const int b_lane = lds0 + (wm * 128 + l31) * 128 + lane_sw;
+    auto frag = [&](int base, int ks, int f) {
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(uint32_t)((base ^ (ks << 5)) + f * 4096));
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = K / BK;                                       // >= 3 (launcher)
+    // prologue: W(0) X(0) W(1) X(1) -> units 0-3
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (u & 1) dma_x(u >> 1, u, i);
+            else dma_w(u >> 1, u, i);
+        }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // own pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa[2][4], fb[2][4];                                   // fragments of the current / the next K step
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { fa[0][f] = frag(a_lane, 0, f); fb[0][f] = frag(b_lane + W4_UNIT, 0, f); }
+
+    // one K tile.  u0 = ring slot of W(t) (X(t): u0 + 1, W(t+1): u0 + 2, X(t+1): u0 + 3, free: u0 + 4; all mod 5)
+    auto tile_body = [&](auto mode_c, int t, int u0) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const int s1 = u0 + 1 >= W4_RING ? u0 + 1 - W4_RING : u0 + 1, s2 = u0 + 2 >= W4_RING ? u0 + 2 - W4_RING : u0 + 2;
+        const int s3 = u0 + 3 >= W4_RING ? u0 + 3 - W4_RING : u0 + 3, s4 = u0 + 4 >= W4_RING ? u0 + 4 - W4_RING : u0 + 4;
+        const int aw = a_lane + u0 * W4_UNIT, ax = b_lane + s1 * W4_UNIT;          // this tile (K steps 1-3)
+        const int awn = a_lane + s2 * W4_UNIT, axn = b_lane + s3 * W4_UNIT;        // next tile (K step 0)
+        gemm_static_for<64>([&acc, &fa, &fb, &frag, &dma_w, &dma_x, aw, ax, awn, axn, t, u0, s4](auto gc) {
+            constexpr int gp = decltype(gc)::value;
+            (void)acc; (void)t; (void)u0; (void)s4; (void)dma_w; (void)dma_x;           // acc: asm operand only; the rest: MODE 1 / 2 request nothing
+            constexpr int ks = gp >> 4, idx = gp & 15, fn = idx >> 2, fm = idx & 3, cur = ks & 1;
+            if constexpr (gp == 48 && MODE < 2) {
+                // the tile's barrier: own pieces of tile t + 1 landed (MODE 0: the 8 pieces of W(t + 2) requested in this tile may fly),
+                // every read of tile t returned
+                if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (idx < 8 && (ks < 3 || MODE < 2)) {      // one fragment of the next K step per gap
+                constexpr int f = idx & 3;
+                if constexpr (ks < 3) {
+                    if constexpr (idx < 4) fa[cur ^ 1][f] = frag(aw, ks + 1, f);
+                    else fb[cur ^ 1][f] = frag(ax, ks + 1, f);
+                } else {
+                    if constexpr (idx < 4) fa[cur ^ 1][f] = frag(awn, 0, f);
+                    else fb[cur ^ 1][f] = frag(axn, 0, f);
+                }
+            }
+#ifndef W4_NO_DMA
+            if constexpr (MODE == 0) {
+                // head: W(t + 2) -> the free unit, one piece per three gaps outside the fragment gaps; tail: X(t + 2) -> W(t)'s unit
+                if constexpr (gp == 8 || gp == 11 || gp == 14 || gp == 24 || gp == 27 || gp == 30 || gp == 40 || gp == 43) {
+                    constexpr int i = gp < 16 ? (gp - 8) / 3 : gp < 32 ? 3 + (gp - 24) / 3 : 6 + (gp - 40) / 3;
+                    dma_w(t + 2, s4, i);
+                }
+                if constexpr (gp >= 56) dma_x(t + 2, u0, gp - 56);
+            }
+#endif
+            asm volatile("v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]" : [d] "+a"(acc[fn][fm]) : [a] "v"(fa[cur][fn]), [b] "v"(fb[cur][fm]));
+        });
+    };
+    int u0 = 0;
+    for (int t = 0; t < nt - 2; ++t) {
+        tile_body(std::integral_constant<int, 0>{}, t, u0);
+        u0 = u0 + 2 >= W4_RING ? u0 + 2 - W4_RING : u0 + 2;
+    }
+    tile_body(std::integral_constant<int, 1>{}, nt - 2, u0);
+    u0 = u0 + 2 >= W4_RING ? u0 + 2 - W4_RING : u0 + 2;
+    tile_body(std::integral_constant<int, 2>{}, nt - 1, u0);
+
+    __syncthreads();                                              // every wave is done with the ring (nothing is in flight: MODE 1 drained it)
+#ifdef W4_NO_STORE
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"a"(acc[i][j]));
+    return;
+#endif
+    if constexpr (EPI == EPI_F32 || EPI == EPI_SWIGLU) {
+        gemm_epilogue<EPI, 4, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 128, l31, hi);
+    } else {
+        gemm_epilogue_lds<EPI, 4>(acc, bias, colscale, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 16384);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp8 (e4m3 x e4m3 -> fp32) twin of the ping-pong kernel for the fp8 configuration's ViT / prefill GEMMs (DotsConfig.fp8_weights):
 //     C[m][n] = epilogue( (sum_k Aq[m][k] Wq[n][k]) * rowscale[m] * colscale[n] + bias[n] )
 // Aq = per-token quantised activations (quant.hip: quant_act_fp8), Wq = per-output-channel quantised weights, both row-major bytes.
@@ -645,6 +816,20 @@ static int raster_group_m(int row_bytes) {
     return panel >= (4 << 20) ? 2 : panel >= (3 << 19) ? 4 : GROUP_M;
 }
 
+// launch plan of the 256-wide bf16 GEMM (process-wide; results are bit-identical under either plan: the same MFMAs in the same k order
+// per output element): 0 = 8 waves, ping-pong halves (round 2), 1 = 4 waves, one per SIMD, K tiles of 64 through a 5-unit ring (round 5)
+static int g_gemm_plan = -1;
+int gemm_get_plan() {
+    int p = __atomic_load_n(&g_gemm_plan, __ATOMIC_RELAXED);
+    if (p < 0) {
+        const char* ev = getenv("DOTS_OCR_GEMM_PLAN");
+        p = ev ? (atoi(ev) != 0) : 0;
+        __atomic_store_n(&g_gemm_plan, p, __ATOMIC_RELAXED);
+    }
+    return p;
+}
+void gemm_set_plan(int plan) { __atomic_store_n(&g_gemm_plan, plan != 0, __ATOMIC_RELAXED); }
+
 template <int E>
 static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const float* colscale, const bf16_t* R, void* C,
                                 int M, int N, int K, int lda, int ldc) {
@@ -664,6 +849,17 @@ static hipError_t launch_256(hipStream_t s, const bf16_t* A, const bf16_t* W, co
     if (lockstep || ldc % 8 != 0) {                 // the LDS-staged epilogue stores 16 bytes per lane
         hipLaunchKernelGGL(gemm_bf16_256_kernel<E>, dim3(m_tiles * n_tiles), dim3(512), 2 * STAGE2, s, A, W, bias, colscale, R, C, M, N, K,
                            lda, ldc, m_tiles, n_tiles);
+        return hipGetLastError();
+    }
+    if (gemm_get_plan() == 1 && K / BK >= 3) {                  // round 5: one wave per SIMD (dots_set_gemm_plan)
+        static uint32_t configured_w4 = 0;
+        if (!(__atomic_load_n(&configured_w4, __ATOMIC_ACQUIRE) & bit)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_RING * W4_UNIT);
+            if (e != hipSuccess) return e;
+            __atomic_fetch_or(&configured_w4, bit, __ATOMIC_RELEASE);
+        }
+        hipLaunchKernelGGL(gemm_bf16_w4_kernel<E>, dim3(m_tiles * n_tiles), dim3(256), W4_RING * W4_UNIT, s, A, W, bias, colscale, R, C, M, N, K,
+                           lda, ldc, m_tiles, n_tiles, raster_group_m(K * 2));
         return hipGetLastError();
     }
     static uint32_t configured_pp = 0;

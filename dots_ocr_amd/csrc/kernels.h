@@ -12,6 +12,8 @@ enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4
 // ---- gemm.hip
 hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R,
                        void* C, int64_t M, int N, int K, int lda, int ldc, int epi, const float* colscale = nullptr);
+int gemm_get_plan();            // 0 = 8-wave ping-pong kernel, 1 = one wave per SIMD (gemm.hip); process-wide
+void gemm_set_plan(int plan);
 // colscale: fp32 [N] multiplied into the accumulator column before bias (fp8 weights: W holds bf16(q), quant.hip), or nullptr
 
 // ---- elementwise.hip

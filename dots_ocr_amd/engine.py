@@ -73,6 +73,7 @@ def _prototypes(lib):
         "dots_preprocess_image": (i32, [vp, vp, i32, i32, i32, i32, i32, P(i32), P(i32), i32, P(i32), P(i32), i32, P(f32), P(f32), f32, vp]),
         "dots_set_sampling": (i32, [vp, f32, f32, C.c_uint64]),
         "dots_set_decode_plan": (i32, [vp, i32]),
+        "dots_set_gemm_plan": (i32, [vp, i32]),
         "dots_slot_capacity": (i32, [vp, i32, P(i32), P(i32)]),
         "dots_slots_reset": (i32, [vp]),
         "dots_set_eos": (i32, [vp, P(i32), i32]),
@@ -118,7 +119,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_get_logits",
+    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_set_gemm_plan", "dots_get_logits",
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info", "dots_slot_capacity", "dots_slots_reset",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
@@ -315,6 +316,10 @@ class Engine:
         """0 = launch plan by stream (whole chip / CU partition beside a prefetched tower), 1 = the partition plan (whole-tile projections,
         pair-walking gate|up) on every step; bit-identical results."""
         self._ck(self.lib.dots_set_decode_plan(self.h, int(plan)), "dots_set_decode_plan")
+
+    def set_gemm_plan(self, plan: int):
+        """0 = 8-wave ping-pong GEMM, 1 = one wave per SIMD (round 5); process-wide, bit-identical results."""
+        self._ck(self.lib.dots_set_gemm_plan(self.h, int(plan)), "dots_set_gemm_plan")
 
     def decode_step(self):
         self._ck(self.lib.dots_decode_step(self.h), "dots_decode_step")

@@ -164,6 +164,12 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
  * projections as whole 16-row tiles (half as many workgroups) and gate|up as one resident round of workgroups that walk the tile pairs.
  * 1 = the partition plan on every step (tests, A/B runs; slower on the whole chip).  Environment DOTS_OCR_DECODE_PLAN sets the default. */
 int dots_set_decode_plan(DotsEngine* e, int plan);
+/* Launch plan of the 256-wide bf16 MFMA GEMM behind the vision tower and the prefill (results are bit-identical under either plan:
+ * the same MFMAs in the same k order per output element).  0 = 8 waves per workgroup, two per SIMD running half a K sub-tile apart
+ * (round 2); 1 = 4 waves, one per SIMD owning a 128 x 128 output block in 256 accumulator registers, K tiles of 64 streamed by LDS-DMA
+ * through a 5-unit ring, one barrier per 64 MFMAs (round 5).  PROCESS-wide (the kernels are shared by every engine of the process);
+ * environment DOTS_OCR_GEMM_PLAN sets the default. */
+int dots_set_gemm_plan(DotsEngine* e, int plan);
 
 /* ---- Continuous batching (the serving loop the reference delegates to vLLM: README "vLLM inference", parser.py:138-166
  * fires one request per page at it and the server keeps its batch full).  The engine's max_batch KV slots are
