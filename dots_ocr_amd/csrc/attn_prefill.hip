@@ -740,10 +740,16 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
     };
     if (flash_rows_per_block() == 256) {
         if (mode == 2 && !causal) {
-            static bool attr_done = false;            // one device per process image in practice; the attribute call is idempotent
-            if (!attr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+            // dynamic LDS > 64 KB is opted into once per DEVICE (engines on several GPUs may live in one process): bit d of the mask
+            static uint32_t attr_done = 0;
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return e;
+            const uint32_t bit = 1u << (dev & 31);
+            if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
                 if (e != hipSuccess) return e;
+                __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
             }
             hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
             return hipGetLastError();

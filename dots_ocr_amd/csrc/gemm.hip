@@ -35,7 +35,21 @@ constexpr int TILE_BYTES = 128 * 128;            // one operand tile: 128 rows x
 constexpr int GROUP_M = GEMM_GROUP_M;
 
 DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// silu(x) = x / (1 + e^-x).  The IEEE division hipcc emits for the plain expression is ~12 VALU instructions (v_div_scale x2, rcp, 4 fma,
+// v_div_fmas, v_div_fixup); 128 of them per lane made the SwiGLU epilogue of the one-wave-per-SIMD kernel 17 k cycles per tile against
+// 9 k for a plain one (profiles/r05_gemm_w4_cycle_stamps.txt).  Here: reciprocal + ONE Newton correction of the quotient (error < 1 ulp
+// of fp32 before the single rounding to bf16; the exponent is clamped so that 1 + e^-x stays finite and 0 * inf cannot appear).
+// -DGEMM_EXACT_SILU restores the division.
+#ifdef GEMM_EXACT_SILU
 DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
+#else
+DEVI float silu(float x) {
+    const float d = 1.0f + __expf(fminf(-x, 80.f));
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, x), r, q);
+}
+#endif
 
 // ---- epilogue shared by both tile shapes: lane owns (m, 4 consecutive n) per (fn, fm, rq) of its 64x64 wave tile.
 // nw0 = first weight row (n) of the wave tile, mw0 = first activation row (m) of the wave tile.
@@ -542,6 +556,135 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256pp_kernel(
 // re-filled behind the same barrier, which every wave passes only with all its reads of tile t returned (lgkmcnt(0)).
 constexpr int W4_UNIT = 256 * 128, W4_RING = 5;
 
+// ---- epilogue of the one-wave-per-SIMD kernel.  Same arithmetic, same LDS transposition and the same full-line stores as
+// gemm_epilogue_lds, but scheduled for a wave that is ALONE on its SIMD: there nothing hides a round trip, and the straight
+// version (write 16, then 8 x {read 2, wait, load residual, wait, store}) measured 7 us per tile without and 17-21 us with a residual
+// (profiles/r05_gemm_ab_first.txt: a third of the kernel at K = 1536) — on 64 CUs as on 256, i.e. latency, not bandwidth
+// (profiles/r05_gemm_epilogue_probe.txt).  Here every round trip is taken once per 32-row block: the residual rows of block
+// fm + 1 and its 16 ds_write_b128 are issued BEFORE block fm is read back (two 16-KB images per wave), the 16 ds_read_b128 of a block
+// are issued together, and the 8 stores of a block follow each other.
+// per-lane column constants of the epilogue (scale, bias of the lane's 8 output columns; SwiGLU: of the 8 gate and the 8 up columns):
+// fetched by vector loads at kernel start — the straight version's 16-32 scalarised loads, each behind its own branch and wait,
+// were a dozen serial round trips per tile on their own
+struct W4Cols { float sc0[8], bi0[8], sc1[8], bi1[8]; };
+template <bool SW>
+DEVI void w4_load_cols(W4Cols& cc, const bf16_t* __restrict__ bias, const float* __restrict__ colscale, int nw0, int l) {
+    const int gcol = SW ? ((l & 7) >> 2) * 64 + (l & 3) * 8 : (l & 15) * 8;
+    u32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    f32x4 s00 = {1.f, 1.f, 1.f, 1.f}, s01 = s00, s10 = s00, s11 = s00;
+    if (bias) {
+        b0 = *reinterpret_cast<const u32x4*>(bias + nw0 + gcol);
+        if (SW) b1 = *reinterpret_cast<const u32x4*>(bias + nw0 + gcol + 32);
+    }
+    if (colscale) {
+        s00 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol);
+        s01 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol + 4);
+        if (SW) {
+            s10 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol + 32);
+            s11 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol + 36);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cc.sc0[e] = s00[e]; cc.sc0[4 + e] = s01[e]; cc.sc1[e] = s10[e]; cc.sc1[4 + e] = s11[e];
+        cc.bi0[2 * e] = lo_bf(b0[e]); cc.bi0[2 * e + 1] = hi_bf(b0[e]);
+        cc.bi1[2 * e] = lo_bf(b1[e]); cc.bi1[2 * e + 1] = hi_bf(b1[e]);
+    }
+}
+
+// FULL: every row of the wave tile is inside the matrix (all tiles but the ragged last m-tile): no per-row guards, so nothing splits the
+// blocks of loads / stores
+template <int EPI, bool FULL>
+DEVI void w4_epilogue_lds(const f32x16 (&acc)[4][4], const W4Cols& cc, bool has_cols, const bf16_t* R,
+                          bf16_t* __restrict__ C, int M, int ldc, int nw0, int mw0, int l, char* stage2) {
+    const int hi = l >> 5, l31 = l & 31;
+    constexpr bool SW = EPI == EPI_SWIGLU;
+    constexpr int ITS = SW ? 4 : 8, RPI = SW ? 8 : 4;            // iterations per 32-row block, rows per iteration
+    const int rrow = SW ? (l >> 3) : (l >> 4);
+    const int gcol = SW ? ((l & 7) >> 2) * 64 + (l & 3) * 8 : (l & 15) * 8;          // first of the lane's 8 (gate) columns in the wave tile
+    const int col = SW ? nw0 / 2 + ((l & 7) >> 2) * 32 + (l & 3) * 8 : nw0 + gcol;   // first output column
+    u32x4 rr[2][8];                                               // residual rows of two blocks
+    auto load_r = [&](int fm, u32x4 (&dst)[8]) {
+        if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int m = FULL ? mw0 + fm * 32 + it * RPI + rrow : min(mw0 + fm * 32 + it * RPI + rrow, M - 1);
+                dst[it] = *reinterpret_cast<const u32x4*>(R + (size_t)m * ldc + col);
+            }
+        }
+    };
+    const int wslot = (l31 & 15) << 1;
+    char* const wrow = stage2 + l31 * 512;
+#define W4_PUT(FM, IMG)                                                                                                   \
+    _Pragma("unroll") for (int fn = 0; fn < 4; ++fn) _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                     \
+        const f32x4 v = {acc[fn][FM][4 * rq], acc[fn][FM][4 * rq + 1], acc[fn][FM][4 * rq + 2], acc[fn][FM][4 * rq + 3]};   \
+        *reinterpret_cast<f32x4*>(wrow + (IMG) * 16384 + (((fn * 8 + rq * 2 + hi) ^ wslot) << 4)) = v;                      \
+    }
+    load_r(0, rr[0]);
+    W4_PUT(0, 0)
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+        if (fm + 1 < 4) {
+            load_r(fm + 1, rr[(fm + 1) & 1]);
+            if (fm == 0) { W4_PUT(1, 1) } else if (fm == 1) { W4_PUT(2, 0) } else { W4_PUT(3, 1) }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* img = stage2 + (fm & 1) * 16384;
+        f32x4 a[ITS][SW ? 4 : 2];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int row = it * RPI + rrow;
+            const int sw = (row & 15) << 1;
+            const char* rp = img + row * 512;
+            const int s0 = gcol >> 2;
+            a[it][0] = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ sw) << 4));
+            a[it][1] = *reinterpret_cast<const f32x4*>(rp + (((s0 + 1) ^ sw) << 4));
+            if constexpr (SW) {
+                a[it][2] = *reinterpret_cast<const f32x4*>(rp + (((s0 + 8) ^ sw) << 4));
+                a[it][3] = *reinterpret_cast<const f32x4*>(rp + (((s0 + 9) ^ sw) << 4));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int m = mw0 + fm * 32 + it * RPI + rrow;
+            float o[8] = {a[it][0][0], a[it][0][1], a[it][0][2], a[it][0][3], a[it][1][0], a[it][1][1], a[it][1][2], a[it][1][3]};
+            float u[8];
+            if constexpr (SW) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = a[it][2 + (e >> 2)][e & 3];
+            }
+            if (has_cols) {                                       // wave-uniform: no bias and no column scale -> o * 1 + 0 is skipped (exact)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = o[e] * cc.sc0[e] + cc.bi0[e];
+                if constexpr (SW) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = u[e] * cc.sc1[e] + cc.bi1[e];
+                }
+            }
+            if constexpr (SW) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = silu(o[e]) * u[e];
+            }
+            if constexpr (EPI == EPI_RESIDUAL) {
+                const u32x4 r4 = rr[fm & 1][it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] += lo_bf(r4[e]); o[2 * e + 1] += hi_bf(r4[e]); }
+            }
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = gelu_erf(o[e]);
+            }
+            if (FULL || m < M) {
+                const u32x4 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+                *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + col) = pk;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef W4_PUT
+}
+
 template <int... I, class F> DEVI void gemm_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEVI void gemm_static_for(F&& f) { gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
@@ -598,6 +741,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
         return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)(uint32_t)((base ^ (ks << 5)) + f * 4096));
     };
 
+#ifdef W4_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pw0 = wall_clock64();
+#endif
+    W4Cols cols;                                                 // the epilogue's column constants: their latency hides behind the main loop
+    if constexpr (EPI != EPI_F32) w4_load_cols<EPI == EPI_SWIGLU>(cols, bias, colscale, n0 + wn * 128, l);
+
     f32x16 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -607,6 +756,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = K / BK;                                       // >= 3 (launcher)
+#ifdef W4_STAGGER
+    // experiment: the first round's workgroups start in 8 phases an eighth of a tile period apart, so that the CUs do not reach their
+    // epilogues (128 KB of stores each) all at once
+    if (blockIdx.x < 256) {
+        const int naps = ((blockIdx.x >> 3) & 7) * nt * W4_STAGGER / 8;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     // prologue: W(0) X(0) W(1) X(1) -> units 0-3
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -620,6 +777,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
     bf16x8 fa[2][4], fb[2][4];                                   // fragments of the current / the next K step
 #pragma unroll
     for (int f = 0; f < 4; ++f) { fa[0][f] = frag(a_lane, 0, f); fb[0][f] = frag(b_lane + W4_UNIT, 0, f); }
+#ifdef W4_PROF
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime(), pw1 = wall_clock64();
+#endif
 
     // one K tile.  u0 = ring slot of W(t) (X(t): u0 + 1, W(t+1): u0 + 2, X(t+1): u0 + 3, free: u0 + 4; all mod 5)
     auto tile_body = [&](auto mode_c, int t, int u0) {
@@ -671,6 +831,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
     u0 = u0 + 2 >= W4_RING ? u0 + 2 - W4_RING : u0 + 2;
     tile_body(std::integral_constant<int, 2>{}, nt - 1, u0);
 
+#ifdef W4_PROF
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime(), pw2 = wall_clock64();
+#endif
     __syncthreads();                                              // every wave is done with the ring (nothing is in flight: MODE 1 drained it)
 #ifdef W4_NO_STORE
 #pragma unroll
@@ -679,11 +842,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
         for (int j = 0; j < 4; ++j) asm volatile("" ::"a"(acc[i][j]));
     return;
 #endif
+#ifdef W4_OLD_EPILOGUE
     if constexpr (EPI == EPI_F32 || EPI == EPI_SWIGLU) {
         gemm_epilogue<EPI, 4, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 128, l31, hi);
     } else {
         gemm_epilogue_lds<EPI, 4>(acc, bias, colscale, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 16384);
     }
+#else
+    if constexpr (EPI == EPI_F32) {
+        gemm_epilogue<EPI, 4, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 128, l31, hi);
+    } else if (m0 + wm * 128 + 128 <= M) {                       // wave-uniform
+        w4_epilogue_lds<EPI, true>(acc, cols, bias != nullptr || colscale != nullptr, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 32768);
+    } else {
+        w4_epilogue_lds<EPI, false>(acc, cols, bias != nullptr || colscale != nullptr, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 32768);
+    }
+#endif
+#ifdef W4_PROF
+    const unsigned long long pt2b = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pt3 = __builtin_amdgcn_s_memtime(), pw3 = wall_clock64();
+    if ((blockIdx.x == 1000 || blockIdx.x == 2001 || blockIdx.x == 3002) && tid == 0)
+        printf("W4_PROF epi %d N %d K %d blk %d: prologue %llu cyc / %.2f us, main loop %llu cyc / %.2f us (%.0f cyc per K tile), epilogue + drain %llu cyc / %.2f us; issue %llu drain %llu\n", EPI, N, K,
+               (int)blockIdx.x, pt1 - pt0, (pw1 - pw0) * 0.01, pt2 - pt1, (pw2 - pw1) * 0.01, (double)(pt2 - pt1) / nt, pt3 - pt2, (pw3 - pw2) * 0.01, pt2b - pt2, pt3 - pt2b);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -823,7 +1004,7 @@ int gemm_get_plan() {
     int p = __atomic_load_n(&g_gemm_plan, __ATOMIC_RELAXED);
     if (p < 0) {
         const char* ev = getenv("DOTS_OCR_GEMM_PLAN");
-        p = ev ? (atoi(ev) != 0) : 0;
+        p = ev ? (atoi(ev) != 0) : 1;      // round 5 default: one wave per SIMD (+6-11 % on the A4 shapes, profiles/r05_gemm_*.txt)
         __atomic_store_n(&g_gemm_plan, p, __ATOMIC_RELAXED);
     }
     return p;

@@ -334,22 +334,27 @@ class PdfDocument:
                 break                                     # image codec: left to PIL (image())
             else:
                 raise PdfContentNotSupported(f"stream filter {f}")
+            if len(raw) > MAX_STREAM_BYTES:
+                raise ValueError(f"PDF stream decodes beyond {MAX_STREAM_BYTES >> 20} MiB")
         return raw
 
-    def _walk(self, node, inherited, _seen=None, _depth=0):
+    def _walk(self, node, inherited, _path=None, _depth=0):
         if not isinstance(node, dict):
             return
-        _seen = set() if _seen is None else _seen
-        if id(node) in _seen or _depth > 64 or len(self.pages) >= MAX_PAGES:      # /Kids cycles, absurd nesting, page bombs
+        # only the ANCESTORS on the current path can close a cycle: the same page object listed twice under /Kids (some generators do
+        # that) is a repeated page, not a malformed tree; depth and the page count bound everything else
+        _path = set() if _path is None else _path
+        if id(node) in _path or _depth > 64 or len(self.pages) >= MAX_PAGES:      # /Kids cycles, absurd nesting, page bombs
             raise ValueError("malformed PDF page tree (cycle, depth > 64 or too many pages)")
-        _seen.add(id(node))
         inh = dict(inherited)
         for k in ("MediaBox", "CropBox", "Resources", "Rotate"):
             if k in node:
                 inh[k] = node[k]
         if node.get("Type") == "Pages" or "Kids" in node:
+            _path.add(id(node))
             for kid in self.get(node.get("Kids")) or []:
-                self._walk(self.get(kid), inh, _seen, _depth + 1)
+                self._walk(self.get(kid), inh, _path, _depth + 1)
+            _path.discard(id(node))
         else:
             self.pages.append(_Page(self, node, inh))
 

@@ -60,6 +60,7 @@ class ContinuousBatcher:
         self._next_id = 0
         self.decode_steps = 0
         self.admissions = 0
+        self._last_lens: Dict[int, int] = {}                     # slot -> tokens generated as of the last poll
         self.kv_truncated = 0                                    # sequences ended early by a dry KV pool (finish reason "kv_pool_exhausted")
         engine.set_eos(list(eos_ids))
         if hasattr(engine, "slots_reset"):           # start from an empty engine: no occupied slot, every KV page in the pool
@@ -85,6 +86,9 @@ class ContinuousBatcher:
         if hasattr(self.engine, "kv_pool_info") and self._admit_pages(ids.shape[0], req.max_new_tokens) > self.engine.kv_pool_info()[0]:
             raise ValueError(f"prompt of {ids.shape[0]} tokens needs {self._admit_pages(ids.shape[0], req.max_new_tokens)} KV pages, "
                              f"the pool holds {self.engine.kv_pool_info()[0]}")
+        if self.full_reservation and hasattr(self.engine, "kv_pool_info") and self._worst_pages(req) > self.engine.kv_pool_info()[0]:
+            raise ValueError(f"prompt + max_new_tokens = {ids.shape[0]} + {req.max_new_tokens} tokens need {self._worst_pages(req)} KV pages under full "
+                             f"reservation, the pool holds {self.engine.kv_pool_info()[0]}")
         rid = self._next_id
         self._next_id += 1
         self.pending.append((rid, req))
@@ -103,6 +107,18 @@ class ContinuousBatcher:
     def _admit_pages(self, prompt: int, max_new: int) -> int:
         return (min(prompt + min(int(max_new), self.ADMIT_AHEAD), self.max_seq_len) + 63) // 64
 
+    def _worst_pages(self, r: Request) -> int:
+        return (min(int(r.input_ids.shape[0]) + int(r.max_new_tokens), self.max_seq_len) + 63) // 64
+
+    def _fits_full_reservation(self, admitted: Sequence[Request], new: Sequence[Request]) -> bool:
+        """Full reservation (headroom_pages=None): the worst case of everything in flight — running, already in this group, prefetched —
+        plus `new` must fit the pool.  Applied on EVERY admission path (ordinary, look-ahead, prefetched group)."""
+        if not self.full_reservation or not hasattr(self.engine, "kv_pool_info"):
+            return True
+        total = self.engine.kv_pool_info()[0]
+        committed = sum(self._worst_pages(r) for _, r in self.running.values()) + sum(self._worst_pages(r) for r in admitted)
+        return committed + sum(self._worst_pages(r) for r in new) <= total
+
     def plan_admission(self) -> List[Tuple[int, int, Request]]:
         """FIFO: pop requests while a slot is free and the group fits the ViT and prefill workspaces.
         Lowest slots first, so the decode graph covers as few rows as possible."""
@@ -119,12 +135,8 @@ class ContinuousBatcher:
             # at what its pages hold — stays the exception.  Nothing running: admit whatever fits (submit() checked that it can).
             need = self._admit_pages(t, req.max_new_tokens)
             reserve = self.headroom_pages * (len(self.running) + len(group) + 1) if (self.running or group) else 0
-            if self.full_reservation:                # worst case of everything in flight must fit the pool
-                total = self.engine.kv_pool_info()[0] if hasattr(self.engine, "kv_pool_info") else 1 << 30
-                worst = lambda r: (min(int(r.input_ids.shape[0]) + int(r.max_new_tokens), self.max_seq_len) + 63) // 64
-                committed = sum(worst(r) for _, r in self.running.values()) + sum(worst(r) for _, _, r in group)
-                if (self.running or group) and committed + worst(req) > total:
-                    break
+            if (self.running or group) and not self._fits_full_reservation([r for _, _, r in group], [req]):
+                break                                # worst case of everything in flight must fit the pool (submit() checked a lone request)
             if need + reserve > pages_free:
                 break                                                                    # wait for a running sequence to return its pages
             pages_free -= need
@@ -177,6 +189,8 @@ class ContinuousBatcher:
             reserve = self.headroom_pages * (len(self.running) + len(self._ahead)) if self.running else 0
             if need + reserve > self.engine.kv_pool_info()[1]:
                 return False
+            if self.running and not self._fits_full_reservation([], [r for _, r in self._ahead]):
+                return False
         group = self._ahead
         try:
             self.engine.vit_take()
@@ -196,12 +210,19 @@ class ContinuousBatcher:
             return
         total_pages = self.engine.kv_pool_info()[0] if hasattr(self.engine, "kv_pool_info") else 1 << 30
         group, patches, tokens, pages = [], 0, 0, 0
-        while self.pending and len(group) < min(self.prefetch, self.n_slots):
+        # A prefetched group goes in only as a whole, and nothing may overtake it: a group larger than the slots that are free or about to
+        # be (within two decode chunks of their cap) would hold freed slots idle while it waits for the rest — with uneven output lengths
+        # (the reference's max_new_tokens=24000) for a long time.  At least one, so that a full engine still hides the next tower.
+        cap = min(self.prefetch, self.n_slots, max(1, len(self.free_slots()) + self._soon_free()))
+        while self.pending and len(group) < cap:
             rid, req = self.pending[0]
             p, t = req.n_patches(), int(req.input_ids.shape[0])
             pg = self._admit_pages(t, req.max_new_tokens)
             if p == 0 or patches + p > self.max_patches or tokens + t > self.max_prefill_tokens or pages + pg > total_pages:
                 break                                # a text-only request goes through the ordinary admission, in its turn
+            if self.full_reservation and sum(self._worst_pages(r) for _, r in group) + self._worst_pages(req) > total_pages:
+                break                                # full reservation: the group must fit an EMPTY pool by its worst case (its tower may run ahead;
+                                                     # _admit_ahead holds it back until it also fits beside what is still running)
             self.pending.popleft()
             group.append((rid, req))
             patches, tokens, pages = patches + p, tokens + t, pages + pg
@@ -215,9 +236,14 @@ class ContinuousBatcher:
             raise
         self._ahead, self._ahead_keep = group, keep
 
+    def _soon_free(self) -> int:
+        """running sequences within two decode chunks of their generation cap (lengths as of the last poll)"""
+        return sum(1 for s, (_, r) in self.running.items() if self._last_lens.get(s, 0) + 2 * self.chunk >= int(r.max_new_tokens))
+
     # ------------------------------------------------------------------ main loop
     def _collect(self) -> List[Tuple[int, Request, np.ndarray]]:
         fin, lens = self.engine.slots_poll()
+        self._last_lens = {s: int(lens[s]) for s in self.running}
         done = []
         for s in sorted(self.running):
             if fin[s] == 1:
@@ -242,7 +268,16 @@ class ContinuousBatcher:
             group = self.plan_admission()
             admitted = bool(group)
             if group:
-                self._admit(group)
+                try:
+                    self._admit(group)
+                except Exception:
+                    # vit_forward / slots_prefill failed: plan_admission popped these requests and nothing registered them yet — put them
+                    # back at the head of the queue (in order) so that the caller's failure handling, which walks `pending`, `running` and
+                    # the prefetched group, finds every request (server.py fails their futures; a lost request would hang its HTTP call)
+                    for s, _, _ in group:
+                        self.running.pop(s, None)
+                    self.pending.extendleft(reversed([(rid, r) for _, rid, r in group]))
+                    raise
         self._look_ahead()
         if admitted:
             done = self._collect()                   # a 1-token cap or an immediate EOS finishes at prefill

@@ -166,8 +166,8 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
 int dots_set_decode_plan(DotsEngine* e, int plan);
 /* Launch plan of the 256-wide bf16 MFMA GEMM behind the vision tower and the prefill (results are bit-identical under either plan:
  * the same MFMAs in the same k order per output element).  0 = 8 waves per workgroup, two per SIMD running half a K sub-tile apart
- * (round 2); 1 = 4 waves, one per SIMD owning a 128 x 128 output block in 256 accumulator registers, K tiles of 64 streamed by LDS-DMA
- * through a 5-unit ring, one barrier per 64 MFMAs (round 5).  PROCESS-wide (the kernels are shared by every engine of the process);
+ * (round 2); 1 (default) = 4 waves, one per SIMD owning a 128 x 128 output block in 256 accumulator registers, K tiles of 64 streamed by
+ * LDS-DMA through a 5-unit ring, one barrier per 64 MFMAs (round 5).  PROCESS-wide (the kernels are shared by every engine of the process);
  * environment DOTS_OCR_GEMM_PLAN sets the default. */
 int dots_set_gemm_plan(DotsEngine* e, int plan);
 

@@ -769,11 +769,11 @@ def test_scheduler_keeps_failed_groups_findable_for_the_callers_error_handling()
         cb.submit(mk(i))
     eng.fail_prefetch = True
     with pytest.raises(RuntimeError, match="tower launch failed"):
-        cb.step()                       # admits 1, 2 — then the look-ahead for 3, 4 fails
+        cb.step()                       # admits 1, 2 — then the look-ahead (3: both slots are busy and far from their caps) fails
     assert sorted(r.tag for _, r in cb.pending) == [3, 4] and not cb._ahead
     eng.fail_prefetch = False
-    cb.step()                            # look-ahead succeeds now
-    assert [r.tag for _, r in cb._ahead] == [3, 4]
+    cb.step()                            # look-ahead succeeds now: ONE request, the engine is full (no group larger than the free slots)
+    assert [r.tag for _, r in cb._ahead] == [3]
     eng.fail_take = True
     with pytest.raises(RuntimeError, match="no rows"):
         for _ in range(50):              # drain 1, 2; the admission of the prefetched group then fails at vit_take
@@ -787,3 +787,76 @@ def test_scheduler_keeps_failed_groups_findable_for_the_callers_error_handling()
     with pytest.raises(RuntimeError, match="cannot be admitted"):
         cb3.step()
     assert len(cb3.pending) == 1
+
+
+def test_scheduler_requeues_the_group_when_the_ordinary_admission_fails():
+    """plan_admission() pops the group from `pending`; if vit_forward or slots_prefill then raises, the requests
+    must go back to the head of the queue (in order) — the server's failure handling walks pending / running / _ahead only, so a
+    request held by none of them would hang its HTTP call.  Covers the first group after start-up, text-only requests, look_ahead=0."""
+    from fakes import FakeSlotEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+
+    class Failing(FakeSlotEngine):
+        fail_vit = fail_prefill = False
+        def vit_forward(self, *a, **k):
+            if self.fail_vit:
+                raise RuntimeError("tower failed")
+            return super().vit_forward(*a, **k)
+        def slots_prefill(self, *a, **k):
+            if self.fail_prefill:
+                raise RuntimeError("prefill failed")
+            return super().slots_prefill(*a, **k)
+    img = lambda i: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), 6, tag=i)
+    txt = lambda i: Request(np.full(8, i, np.int32), None, None, 6, tag=i)
+    for fail, make in (("fail_vit", img), ("fail_prefill", img), ("fail_prefill", txt)):
+        eng = Failing(lambda prompt: int(prompt[0]) + np.arange(64), max_batch=2, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
+        cb = ContinuousBatcher(eng, chunk=4, prefetch=0)
+        ids = [cb.submit(make(i)) for i in range(1, 4)]
+        setattr(eng, fail, True)
+        with pytest.raises(RuntimeError, match="failed"):
+            cb.step()
+        assert [rid for rid, _ in cb.pending] == ids and not cb.running and not cb._ahead and not eng.slots      # nothing lost, order kept
+        setattr(eng, fail, False)
+        out = {}
+        while not cb.idle:
+            for rid, r, toks in cb.step():
+                out[rid] = (r.tag, toks.tolist())
+        assert sorted(out) == ids and all(out[i][1] == (out[i][0] + np.arange(6)).tolist() for i in ids)
+
+
+def test_scheduler_full_reservation_holds_on_the_look_ahead_paths_too():
+    """with headroom_pages=None nothing may ever be truncated by a dry pool — also when image requests enter through
+    the look-ahead (prefetch > 0, the server default); a lone request whose worst case exceeds the pool is refused at submit()."""
+    from fakes import FakePagedEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    script = lambda prompt: int(prompt[0]) * 1000 + np.arange(400)
+    mk = lambda i, cap=300: Request(np.full(40, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), cap)
+    eng = FakePagedEngine(script, pool_pages=12, max_batch=4, max_patches=100, max_prefill_tokens=1 << 20, max_seq_len=1024)
+    cb = ContinuousBatcher(eng, chunk=8, headroom_pages=None, prefetch=4)
+    reqs = [mk(i) for i in range(1, 7)]                    # 6 x (40 + 300) tokens = 6 pages each by worst case: two at a time in 12 pages
+    outs = cb.run(reqs)
+    assert cb.kv_truncated == 0 and eng.capped == 0 and all(len(o) == 300 for o in outs)
+    assert max(len(x[2]) for x in eng.log if x[0] == "decode") == 2
+    assert any(x[0] == "prefetch" for x in eng.log)         # the look-ahead path was exercised
+    with pytest.raises(ValueError, match="full\\s+reservation|under full"):
+        cb.submit(mk(9, cap=900))                          # 40 + 900 tokens = 15 pages > 12
+
+
+def test_scheduler_look_ahead_group_is_capped_by_the_slots_that_are_or_will_soon_be_free():
+    from fakes import FakeSlotEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    mk = lambda i, cap: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), cap, tag=i)
+    eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(4096), max_batch=4, max_patches=100, max_prefill_tokens=64, max_seq_len=8192)
+    cb = ContinuousBatcher(eng, chunk=4, prefetch=4)
+    for i, cap in enumerate([2000, 2000, 2000, 12, 50, 50, 50, 50], 1):
+        cb.submit(mk(i, cap))
+    cb.step()                                              # 1-4 admitted; every slot busy: the look-ahead takes ONE request
+    assert len(cb.running) == 4 and [r.tag for _, r in cb._ahead] == [5]
+    while 4 in [r.tag for _, r in cb.running.values()]:
+        cb.step()
+    # request 4 (12 tokens) finished: its slot went to the prefetched request at once instead of waiting for three more slots
+    steps = 0
+    while 5 not in [r.tag for _, r in cb.running.values()]:
+        cb.step(); steps += 1
+        assert steps < 3
+    assert sum(1 for _, r in cb.running.values() if r.tag in (1, 2, 3)) == 3
