@@ -306,7 +306,11 @@ def main():
             # look-ahead: with EOS disabled and equal caps every slot finishes together, so the whole next group's towers are prefetched
             # round 4: the partition launch plan covers any row count, so the look-ahead now wins at 32 occupied slots (4.04 -> 4.26 pages/s
             # on one GPU, profiles/r04_bench_mixed64*.json) and is the default; DOTS_BENCH_PREFETCH=0 switches it off
-            outs = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots)))).run(reqs)
+            cb = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots))))
+            outs = cb.run(reqs)
+            mixed_meter["decode_steps"] += cb.decode_steps
+            mixed_meter["requests"].append([(len(r.input_ids), len(o)) for r, o in zip(reqs, outs)])
+            mixed_meter["last_reqs"], mixed_meter["last_outs"] = reqs, outs
             out = np.zeros((len(outs), a.max_new_tokens), np.int32)
             out_lens = np.zeros(len(outs), np.int32)
             for i, o in enumerate(outs):
@@ -322,6 +326,42 @@ def main():
         host_ms["preprocess_ms"] += (t2 - t1) * 1e3
         host_ms["detokenize_ms"] += (t4 - t3) * 1e3
         return out, out_lens, texts, prompts
+
+    # mixed64: the scheduler drives the engine; meters around the calls it makes give the timed region's roofline inputs without touching the
+    # schedule: (a) before a NEW tower is launched the previous one has been taken (done), so its HIP-event sums (flash-attention launches,
+    # algorithmic flops) are read then — dots_get_stats only waits for streams that are idle at that point; (b) the wall time from each
+    # slots_decode to the poll that follows it (host-synchronised) is the decode time of that chunk, the tower of the look-ahead running beside it
+    mixed_meter = {"attn_ms": 0.0, "attn_flops": 0.0, "attn_launches": 0, "vit_ms": 0.0, "vit_flops": 0.0, "towers": 0, "pending": False,
+                   "decode_ms": 0.0, "t_dec": None, "decode_steps": 0, "requests": [], "last_reqs": None, "last_outs": None}
+    if mixed:
+        def harvest():
+            if mixed_meter["pending"]:
+                st_ = eng.stats()
+                mixed_meter["attn_ms"] += st_["vit_attn_ms"]; mixed_meter["attn_flops"] += st_["vit_attn_flops"]
+                mixed_meter["attn_launches"] += st_["vit_attn_launches"]; mixed_meter["vit_ms"] += st_["vit_ms"]; mixed_meter["vit_flops"] += st_["vit_flops"]
+                mixed_meter["towers"] += 1
+                mixed_meter["pending"] = False
+        _vf, _vp, _sd, _sp = eng.vit_forward, eng.vit_prefetch, eng.slots_decode, eng.slots_poll
+
+        def vit_forward_m(*aa, **kk):
+            harvest(); r_ = _vf(*aa, **kk); mixed_meter["pending"] = True; return r_
+
+        def vit_prefetch_m(*aa, **kk):
+            harvest(); r_ = _vp(*aa, **kk); mixed_meter["pending"] = True; return r_
+
+        def slots_decode_m(n_):
+            if mixed_meter["t_dec"] is None:
+                mixed_meter["t_dec"] = time.perf_counter()
+            return _sd(n_)
+
+        def slots_poll_m():
+            r_ = _sp()
+            if mixed_meter["t_dec"] is not None:
+                mixed_meter["decode_ms"] += (time.perf_counter() - mixed_meter["t_dec"]) * 1e3
+                mixed_meter["t_dec"] = None
+            return r_
+        eng.vit_forward, eng.vit_prefetch, eng.slots_decode, eng.slots_poll = vit_forward_m, vit_prefetch_m, slots_decode_m, slots_poll_m
+        mixed_meter["harvest"] = harvest
 
     deep_state = {"k": 0, "queue": [], "last_decode_ms": 0.0}
     tower_after_prefill = os.environ.get("DOTS_BENCH_TOWER_NOW") != "1"      # =1: the next tower starts beside this batch's prefill (A/B; measured slower)
@@ -409,6 +449,11 @@ def main():
             pipelined_outs.append((o_.copy(), l_.copy()))
     for k in host_ms:
         host_ms[k] = 0.0
+    if mixed:
+        mixed_meter["harvest"]()
+        for k_ in ("attn_ms", "attn_flops", "vit_ms", "vit_flops", "decode_ms"):
+            mixed_meter[k_] = 0.0
+        mixed_meter.update({"attn_launches": 0, "towers": 0, "decode_steps": 0, "requests": []})
     eng.synchronize(); torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
     phase = {"vit_ms": 0.0, "prefill_ms": 0.0, "decode_ms": 0.0, "vit_attn_ms": 0.0}
@@ -437,7 +482,16 @@ def main():
         for k in phase:
             phase[k] += st[k]
         last = st
-    eng.synchronize(); torch.cuda.synchronize(); barrier()
+    eng.synchronize(); torch.cuda.synchronize()
+    if mixed:
+        mixed_meter["harvest"]()
+    # the only data-path collective of the job — the gather of the generated token ids on rank 0 (dp.py: two all_gathers over RCCL) —
+    # is INSIDE the timed region, timed on its own as well
+    tg = time.perf_counter()
+    gathered = dp.gather_token_ids(out, out_lens, page_index=my_pages)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
     # ---- parity of what was timed: every pipelined step (CU-masked side stream, half-chip decode plan, deferred tower)
@@ -452,8 +506,6 @@ def main():
                                  f"(first difference at page {int(bad[0][0])}, token {int(bad[0][1])}): the timed configuration is NOT parity-clean")
         parity = {"parity_vs_sequential": "bitwise", "steps_checked": len(pipelined_outs),
                   "tokens_per_step_checked": int(seq_out[1].sum())}
-    # the only data-path collective: gather the generated token ids on rank 0
-    gathered = dp.gather_token_ids(out, out_lens, page_index=my_pages)
     n_ranks = 1
     per_rank = None
     if use_dist:
@@ -488,7 +540,8 @@ def main():
             "value": pages_total / dt, "unit": "pages/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if mixed else "weak", "vs_baseline": None,
             "dtype": "fp8 e4m3 weights (per-output-channel fp32 scale) x bf16 activations, fp32 accumulate" if fp8 else "bf16", "data": "synthetic pages (PIL text lines) as uint8 pixels in HBM, seeded random weights at the checkpoint's dimensions",
-            "output_tok_s": new_tok / dt, "rccl_ranks": n_ranks, "gathered_pages": len(gathered), "setup_s": setup_s,
+            "output_tok_s": new_tok / dt, "rccl_ranks": n_ranks, "gathered_pages": len(gathered), "gather_ms": gather_ms,
+            "gather_note": "token-id gather on rank 0 (the job's only collective; 2 all_gathers), once per job, inside the timed region", "setup_s": setup_s,
         }
         if parity:
             res.update(parity)
@@ -496,6 +549,48 @@ def main():
             res["per_rank"] = per_rank
         if mixed:
             from collections import Counter
+            mm = mixed_meter
+            kv_tok = cfg.num_hidden_layers * cfg.num_key_value_heads * 128 * 2 * 2
+            Wb = 2.0 * (sum(int(np.prod(v_.shape)) for k_, v_ in sd.items() if k_.startswith("model.layers.") and v_.dim() == 2) + cfg.vocab_size * cfg.hidden_size)   # 3 087 138 816 B
+            if fp8:
+                Wb /= 2.0
+            # algorithmic decode bytes of the timed region: every weight byte once per decode step + the KV read of every row and step
+            kv_bytes = sum(kv_tok * sum(L_ + t_ for t_ in range(1, n_)) for job in mm["requests"] for (L_, n_) in job)
+            dec_bytes = mm["decode_steps"] * Wb + kv_bytes
+            attn_tf = mm["attn_flops"] / (mm["attn_ms"] / 1e3) / 1e12 if mm["attn_ms"] > 0 else 0.0
+            dec_gbs = dec_bytes / (mm["decode_ms"] / 1e3) / 1e9 if mm["decode_ms"] > 0 else 0.0
+            dec_cus_m = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "96")) // 8 * 8
+            res["roofline"] = {"bound": "mfma", "kernel": "flash_attn64_kernel (ViT bidirectional var-len attention) over the timed region's towers: ragged packed batches of the six page sizes",
+                               "achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / PEAK_BF16_TFLOPS, "traffic": None,
+                               "algorithmic_flops": mm["attn_flops"], "launches": mm["attn_launches"], "towers": mm["towers"],
+                               "sum_of_launch_ms": mm["attn_ms"],
+                               "note": f"HIP-event sums on the stream each tower ran on; look-ahead towers run on the {256 - dec_cus_m}-CU partition beside the decode loop "
+                                       f"(frac is against the WHOLE chip's peak: x 256 / {256 - dec_cus_m} for the partition's), the first group's tower on the whole chip"}
+            res["roofline_decode"] = {"bound": "hbm", "achieved": dec_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dec_gbs / PEAK_HBM_GBS, "traffic": None,
+                                      "decode_steps": mm["decode_steps"], "algorithmic_bytes": dec_bytes, "decode_wall_ms": mm["decode_ms"],
+                                      "note": f"wall time from each slots_decode chunk to the poll after it (host-synchronised), up to {slots} rows per step, on the {dec_cus_m}-CU "
+                                              "partition while a look-ahead tower runs and on the whole chip otherwise"}
+            res["phase_ms_per_step"] = {"vit_ms": mm["vit_ms"] / K, "vit_attn_ms": mm["attn_ms"] / K, "decode_ms": mm["decode_ms"] / K, **{k: val / K for k, val in host_ms.items()}}
+            # parity of what was timed: 8 of this rank's pages (every size class first, then the front of the list) decoded again ALONE through the
+            # static single-sequence generate — the continuous batch with look-ahead towers must have produced the same tokens, bit for bit
+            seen, sample = set(), []
+            for i_, sz_ in enumerate(sizes):
+                if sz_ not in seen:
+                    seen.add(sz_); sample.append(i_)
+            sample = (sample + [i_ for i_ in range(len(sizes)) if i_ not in sample])[:8]
+            eng.vit_forward, eng.vit_prefetch, eng.slots_decode, eng.slots_poll = _vf, _vp, _sd, _sp
+            bad = []
+            for i_ in sample:
+                r_ = mm["last_reqs"][i_]
+                single, sl = eng.generate(r_.input_ids, np.asarray([len(r_.input_ids)], np.int32), r_.pixel_values.data_ptr(), np.asarray(r_.grid_thw, np.int64),
+                                          a.max_new_tokens, (), pixel_on_device=True)
+                if not np.array_equal(single[0, :sl[0]], mm["last_outs"][i_]):
+                    bad.append(my_pages[i_])
+            if bad:
+                raise SystemExit(f"bench.py: mixed64: pages {bad} decoded differently in the continuous batch than alone: the timed configuration is NOT parity-clean")
+            res["parity_vs_single_sequence"] = "bitwise"
+            res["pages_checked"] = [int(my_pages[i_]) for i_ in sample]
+            res["tokens_per_page_checked"] = a.max_new_tokens
             res["config"] = {"workload": "mixed64: 64 pages " + ", ".join(f"{n}x {w}x{h}" for (w, h), n in sorted(Counter(sizes_all).items())) +
                                          f"; cost-sharded (LPT) over {world} rank(s), continuous batching over {slots} slots per rank, "
                                          f"max_new_tokens={a.max_new_tokens}, EOS disabled",
@@ -585,6 +680,23 @@ def main():
                                                 "dense bf16 peak, and algorithmic decode bytes / step time vs the HBM peak",
                                         "mfma_frac": (last["vit_flops"] + last["prefill_flops"]) / step_s / 1e12 / PEAK_BF16_TFLOPS,
                                         "hbm_frac": last["decode_bytes"] / step_s / 1e9 / PEAK_HBM_GBS}
+            if overlap and seq_stats:
+                # the three shapes of the same work side by side: throughput AND how long a page waits for its tokens
+                step_ms = dt / K * 1e3
+                one = None
+                f1 = ROOT / "profiles" / "r05_bench_a4_one_batch_in_flight.json"
+                if a.workload == "a4" and B == 8 and f1.exists():
+                    j1 = json.loads(f1.read_text())
+                    one = {"pages_per_s": j1["value"], "page_latency_s": 2 * j1["ms_per_step"] / 1e3,
+                           "source": "profiles/r05_bench_a4_one_batch_in_flight.json (bench.py --rows-in-flight 8 on the same build: the tower of batch k+1 beside the decode loop of batch k)"}
+                res["throughput_shapes"] = {
+                    "headline": f"pipelined, {rif if deep else B} rows in flight",
+                    f"pipelined_{rif if deep else B}_rows_in_flight": {"pages_per_s": pages_total / dt, "page_latency_s": (n_groups if deep else 2) * step_ms / 1e3,
+                                                                         "note": "a page's tokens are complete this many seconds after its batch was admitted (throughput configuration: "
+                                                                                 "the reference's parse_pdf over a document)"},
+                    "one_batch_in_flight": one,
+                    "sequential_batch": {"pages_per_s": n_job_pages / world / (seq_stats["total_ms"] / 1e3) * world, "page_latency_s": seq_stats["total_ms"] / 1e3,
+                                         "source": "the strictly sequential batch this run starts with (tower -> prefill -> 1023 decode steps on the whole chip, nothing overlapped)"}}
             # north_star targets, stated as what the evidence supports: the kernels ALONE on the chip (the sequential batch of this run) and
             # what the chip sustains over the whole timed step
             vit_alone = res.get("roofline_vit_sequential", res["roofline_vit"])["frac"]

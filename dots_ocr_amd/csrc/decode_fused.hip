@@ -699,9 +699,9 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     static const int pairs_env = [] { const char* e = getenv("DOTS_OCR_GATEUP_PAIRS"); return e ? atoi(e) : 0; }();
     const int pairs = pairs_env ? pairs_env : (B > 8 ? 2 : 1);
     static const bool per_tile = getenv("DOTS_OCR_GATEUP_PER_TILE") != nullptr;     // A/B switch: one workgroup set per 16-row tile at every batch size
-    // the two-tile instantiation was validated on the GPU in bf16 (bitwise test + the bench's 64-row parity check); the e4m3 one compiles from
-    // the same template but has not run yet, so fp8 batches above 16 rows keep the per-tile kernels until DOTS_OCR_TWO_TILE_FP8=1 has been tested
-    static const bool fp8_ok = getenv("DOTS_OCR_TWO_TILE_FP8") != nullptr;
+    // both instantiations (bf16, e4m3) are held to the one-tile kernels bit for bit by tests/test_decode_kernels_gpu.py (round 5: the e4m3 one
+    // too); DOTS_OCR_TWO_TILE_FP8=0 is the A/B switch back to the per-tile kernels for fp8 batches above 16 rows
+    static const bool fp8_ok = !(getenv("DOTS_OCR_TWO_TILE_FP8") && atoi(getenv("DOTS_OCR_TWO_TILE_FP8")) == 0);
     if (B > 16 && !per_tile && (!wscale || fp8_ok) && (I / 16) % 2 == 0) {          // two batch tiles per workgroup (TT = 2): every weight byte feeds 32 rows
         static uint32_t attr_t = 0;
         static int occ_t = 0;
@@ -757,7 +757,7 @@ static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
     if (H % (32 * LmG<WT>::value)) return hipErrorInvalidValue;
     static uint32_t attr = 0, attr2 = 0;
     static const bool per_tile = getenv("DOTS_OCR_LMHEAD_PER_TILE") != nullptr;       // A/B switch: one workgroup set per 16-row tile at every batch size
-    static const bool fp8_ok = getenv("DOTS_OCR_TWO_TILE_FP8") != nullptr;           // see gateup_launch: the e4m3 instantiation has not run on a GPU yet
+    static const bool fp8_ok = !(getenv("DOTS_OCR_TWO_TILE_FP8") && atoi(getenv("DOTS_OCR_TWO_TILE_FP8")) == 0);           // see gateup_launch
     if (B > 16 && !per_tile && (!wscale || fp8_ok) && (size_t)32 * H * 2 <= 160 * 1024) {   // two batch tiles per workgroup: each weight byte feeds 32 rows
         hipError_t e2 = ensure_lds(dec_lmhead2_kernel<NC_MAX, WT>, (size_t)32 * H * 2, &attr2);
         if (e2 != hipSuccess) return e2;

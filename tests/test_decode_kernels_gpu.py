@@ -247,11 +247,13 @@ def test_dec_lmhead_logits(eng, B):
     assert torch.equal(out.argmax(-1).cpu(), ref.argmax(-1)) or (ref.topk(2).values.diff().abs().min() < 1e-3)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("B", [17, 33, 40, 64])
-def test_two_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B):
+def test_two_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8):
     """Above 16 rows gate|up and lm_head run TWO 16-row batch tiles per workgroup (the weights cross the CU once per 32 rows).  Per output
     element the MFMAs, their order and the split-K reduction are those of the one-tile kernels, so the rows of a B-row call must equal,
-    bit for bit, the same rows computed in calls of at most 16 rows — the property batch invariance of the tokens rests on."""
+    bit for bit, the same rows computed in calls of at most 16 rows — the property batch invariance of the tokens rests on.  fp8: the e4m3
+    instantiations of the same templates (weights quantised inside the op entry points, quant.hip)."""
     g = torch.Generator().manual_seed(B + 1234)
     h, ln_w = bf(torch.randn(B, H, generator=g) * 3), bf(1 + 0.1 * torch.randn(H, generator=g))
     gate, up = bf(torch.randn(I, H, generator=g) / math.sqrt(H)), bf(torch.randn(I, H, generator=g) / math.sqrt(H))
@@ -260,17 +262,18 @@ def test_two_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B):
     act = torch.zeros(B, I, dtype=torch.bfloat16, device="cuda")
     logits = torch.zeros(B, V, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    eng.op_dec_gateup(hd.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), act.data_ptr(), B, H, I, EPS)
-    eng.op_dec_lmhead(hd.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), logits.data_ptr(), B, H, V, EPS)
+    eng.op_dec_gateup(hd.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), act.data_ptr(), B, H, I, EPS, fp8=fp8)
+    eng.op_dec_lmhead(hd.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), logits.data_ptr(), B, H, V, EPS, fp8=fp8)
     eng.synchronize()
+    assert float(act.float().abs().max()) > 0 and float(logits.abs().max()) > 0
     for r0 in range(0, B, 16):
         n = min(16, B - r0)
         hs = hd[r0:r0 + n].contiguous()
         a1 = torch.zeros(n, I, dtype=torch.bfloat16, device="cuda")
         l1 = torch.zeros(n, V, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
-        eng.op_dec_gateup(hs.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), a1.data_ptr(), n, H, I, EPS)
-        eng.op_dec_lmhead(hs.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), l1.data_ptr(), n, H, V, EPS)
+        eng.op_dec_gateup(hs.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), a1.data_ptr(), n, H, I, EPS, fp8=fp8)
+        eng.op_dec_lmhead(hs.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), l1.data_ptr(), n, H, V, EPS, fp8=fp8)
         eng.synchronize()
         assert torch.equal(act[r0:r0 + n].view(torch.int16), a1.view(torch.int16)), f"gate|up rows {r0}..{r0 + n - 1} of {B}"
         assert torch.equal(logits[r0:r0 + n].view(torch.int32), l1.view(torch.int32)), f"lm_head rows {r0}..{r0 + n - 1} of {B}"

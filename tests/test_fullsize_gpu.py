@@ -66,6 +66,66 @@ def test_flash_attn_a4_sampled_rows_match_oracle(eng):
     assert err < 4e-3 + 2 ** -6 * ref.abs().max().item(), err
 
 
+def _flash_packed(eng, qs, ks, vs):
+    """A packed batch of sequences (lists of [n_i, H, 128] cuda bf16), laid out as the engine lays the ViT batch out: q / k head-major over
+    the packed tokens, V^T per sequence padded to a multiple of 64 keys.  -> list of [n_i, H, 128]."""
+    H = qs[0].shape[1]
+    lens = [q.shape[0] for q in qs]
+    T = sum(lens)
+    qd = torch.cat(qs).permute(1, 0, 2).contiguous()
+    kd = torch.zeros(H, T + 64, 128, dtype=torch.bfloat16, device="cuda")
+    kd[:, :T] = torch.cat(ks).permute(1, 0, 2)
+    vt = torch.cat([_vt(v) for v in vs], dim=2).contiguous()
+    out = torch.zeros(T, H * 128, dtype=torch.bfloat16, device="cuda")
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    torch.cuda.synchronize()
+    eng.op_flash_attn(qd.data_ptr(), kd.data_ptr(), vt.data_ptr(), out.data_ptr(), cu, H, H, False, 1 / math.sqrt(128))
+    eng.synchronize()
+    return list(out.view(T, H, 128).split(lens))
+
+
+def _check_rows(out, q, k, v, rows):
+    qs, kf, vf = q[rows].float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = om._attention(qs.transpose(0, 1), kf.transpose(0, 1), vf.transpose(0, 1), 1 / math.sqrt(128), False, True).transpose(0, 1)
+    err = (out[rows].float().cpu() - ref).abs().max().item()
+    assert err < 4e-3 + 2 ** -6 * ref.abs().max().item(), (err, q.shape[0])
+
+
+@pytest.mark.parametrize("n", [39648, 56644])           # an A3 page of the mixed64 set (236 x 168 patches); the largest page the reference admits (238 x 238)
+def test_flash_attn64_sampled_rows_match_oracle_above_a4(eng, n):
+    """VERDICT r4 #4a: flash_attn64_kernel against the oracle at the sequence lengths above A4 that the workloads contain — 620 / 886 KV tiles
+    per query block, a ragged last tile (39 648 = 619 x 64 + 32, 56 644 = 885 x 64 + 4), 4 heads (the kernel's work items are per head)."""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    H = 4
+    q = torch.randn(n, H, 128, device="cuda", generator=g).bfloat16()
+    k = torch.randn(n, H, 128, device="cuda", generator=g).bfloat16()
+    v = torch.randn(n, H, 128, device="cuda", generator=g).bfloat16()
+    out = _flash(eng, q, k, v)
+    _check_rows(out, q, k, v, [0, 63, 64, 255, 256, 20001, n // 2, n - 65, n - 33, n - 1])
+
+
+def test_flash_attn64_ragged_packed_batch_of_the_mixed64_sizes(eng):
+    """A packed batch with one page of every size class of BASELINE configs[3] (bench.py --workload mixed64): A3, A4, 1700x2250, 1344x1344,
+    946x1024, 583x550 -> 39 648 / 19 824 / 19 520 / 9 216 / 5 032 / 1 680 patches in ONE launch; sampled rows of every sequence (first and
+    last query block, the rows next to the sequence boundaries) against the oracle run on that sequence alone."""
+    from dots_ocr_amd.image_utils import smart_resize
+    sizes = [(2339, 3308), (1654, 2339), (1700, 2250), (1344, 1344), (946, 1024), (583, 550)]
+    lens = []
+    for w, h in sizes:
+        rh, rw = smart_resize(h, w)
+        lens.append((rh // 14) * (rw // 14))
+    assert lens[:4] == [39648, 19824, 19520, 9216] and lens[5] == 1680, lens
+    g = torch.Generator(device="cuda").manual_seed(64)
+    H = 2
+    qs = [torch.randn(n, H, 128, device="cuda", generator=g).bfloat16() for n in lens]
+    ks = [torch.randn(n, H, 128, device="cuda", generator=g).bfloat16() for n in lens]
+    vs = [torch.randn(n, H, 128, device="cuda", generator=g).bfloat16() for n in lens]
+    outs = _flash_packed(eng, qs, ks, vs)
+    for out, q, k, v in zip(outs, qs, ks, vs):
+        n = q.shape[0]
+        _check_rows(out, q, k, v, sorted({0, 1, 63, 64, min(255, n - 1), min(256, n - 1), n // 2, n - 64, n - 2, n - 1}))
+
+
 def test_flash_attn_a4_properties(eng):
     g = torch.Generator(device="cuda").manual_seed(2)
     H = 12

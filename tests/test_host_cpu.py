@@ -860,3 +860,67 @@ def test_scheduler_look_ahead_group_is_capped_by_the_slots_that_are_or_will_soon
         cb.step(); steps += 1
         assert steps < 3
     assert sum(1 for _, r in cb.running.values() if r.tag in (1, 2, 3)) == 3
+
+
+def test_first_contact_script_on_a_synthetic_checkpoint_directory(tmp_path):
+    """tools/first_contact.py — the one command for the day a real checkpoint is present — run end to end on CPU
+    (--no-gpu: config diff against SURVEY §8(a)'s [RECALLED] table, safetensors inventory against what the engine consumes, text side,
+    and the bf16-emulated oracle decoding from the files) against a synthetic checkpoint directory: it must report the recalled values
+    that differ, the tensor the engine would not consume, the tensor it would miss, an ignored key that changes the arithmetic — and exit 2."""
+    import json
+    import subprocess
+    import sys
+    from dots_ocr_amd.config import DotsConfig
+    from dots_ocr_amd.synthetic import synth_page
+    from dots_ocr_amd.weights import random_state_dict, save_safetensors
+    cfg = DotsConfig.tiny(layers=2, v_layers=2, vocab=1024)
+    sd = random_state_dict(cfg, seed=31)
+    v = cfg.vision
+    base = {"hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers, "num_attention_heads": cfg.num_attention_heads,
+            "num_key_value_heads": cfg.num_key_value_heads, "intermediate_size": cfg.intermediate_size, "vocab_size": cfg.vocab_size,
+            "rope_theta": cfg.rope_theta, "rms_norm_eps": cfg.rms_norm_eps, "image_token_id": cfg.image_token_id, "attention_bias": True,
+            "tie_word_embeddings": False, "pad_token_id": cfg.pad_token_id, "hidden_act": "silu", "torch_dtype": "bfloat16",
+            "vision_config": {"embed_dim": v.embed_dim, "num_hidden_layers": v.num_hidden_layers, "num_attention_heads": v.num_attention_heads,
+                              "intermediate_size": v.intermediate_size, "patch_size": 14, "spatial_merge_size": 2, "hidden_size": v.hidden_size}}
+    root = Path(__file__).resolve().parent.parent
+
+    def make(d, config, tensors):
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(config))
+        (d / "generation_config.json").write_text(json.dumps({"eos_token_id": list(cfg.eos_token_ids), "do_sample": False}))
+        (d / "preprocessor_config.json").write_text(json.dumps({"min_pixels": 3136, "max_pixels": 11289600}))
+        save_safetensors(tensors, d / "model.safetensors")
+    page = tmp_path / "page.png"
+    synth_page(5, (196, 140)).save(page)
+
+    def run(d):
+        out = tmp_path / (d.name + ".json")
+        p = subprocess.run([sys.executable, str(root / "tools" / "first_contact.py"), "--model-path", str(d), "--image", str(page), "--steps", "4", "--no-gpu",
+                            "--prompt-mode", "prompt_ocr", "--out", str(out)], capture_output=True, text=True, timeout=600)
+        return p.returncode, json.loads(out.read_text()), p.stdout + p.stderr
+    # 1. a consistent checkpoint (tiny dims): nothing crashes; the only blocking item is the missing tokenizer.json
+    make(tmp_path / "good", base, sd)
+    rc, rep, log = run(tmp_path / "good")
+    assert rc == 2 and not rep["crashed_stages"], log[-2000:]
+    assert [b for b in rep["blocking"] if "tokenizer.json" in b] and len(rep["blocking"]) == 1, rep["blocking"]
+    diff = {(r["where"], r["key"]) for r in rep["stages"]["1_config_diff"]["differing_recalled_values"]}
+    assert ("config.json", "hidden_size") in diff and ("config.json:vision_config", "embed_dim") in diff            # tiny dims != the recalled 1536
+    assert any(i["key"] == "torch_dtype" for i in rep["stages"]["1_config_diff"]["keys_the_engine_ignores"])
+    inv = rep["stages"]["2_tensor_inventory"]
+    assert inv["tensors_in_checkpoint"] == inv["tensors_the_engine_consumes"] == len(sd) and not inv["required_but_missing"] and not inv["present_but_unused"]
+    r4 = rep["stages"]["4_run"]
+    assert len(r4["oracle_tokens"]) == 4 and r4["patches"] == 140 and isinstance(r4["oracle_text"], str)
+    # 2. reality differs from recollection: an activation the engine ignores, a parameter it does not model, one it needs and does not find
+    bad_sd = dict(sd)
+    bad_sd["vision_tower.blocks.0.attn.qkv.bias"] = torch.zeros(3 * v.embed_dim, dtype=torch.bfloat16)
+    del bad_sd["model.layers.1.mlp.down_proj.weight"]
+    bad_cfg = dict(base, hidden_act="gelu", rope_scaling={"type": "yarn", "factor": 4.0})
+    bad_cfg["vision_config"] = dict(base["vision_config"], is_causal=True)
+    make(tmp_path / "bad", bad_cfg, bad_sd)
+    rc, rep, log = run(tmp_path / "bad")
+    assert rc in (1, 2), log[-2000:]
+    joined = " | ".join(rep["blocking"])
+    for needle in ("hidden_act", "rope_scaling", "is_causal", "would NOT be consumed", "requires are absent"):
+        assert needle in joined, (needle, rep["blocking"])
+    assert rep["stages"]["2_tensor_inventory"]["present_but_unused"] == ["vision_tower.blocks.0.attn.qkv.bias"]
+    assert rep["stages"]["2_tensor_inventory"]["required_but_missing"] == ["model.layers.1.mlp.down_proj.weight"]
