@@ -269,6 +269,208 @@ __global__ __launch_bounds__(NW * 64, ONE ? 3 : 2) void decode_attn_kernel(const
     TRACE(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5: STREAMING decode attention for many (row, kv head, split) items per CU — the 64-row step of the pipelined bench on its 64-CU
+// partition.  The kernel above is one short-lived workgroup per item: two dependent round trips (context / page id / q, then the page),
+// 128 KB moved, an LDS combine and 3 KB of partials — 3200 of them at 64 rows x 25 splits.  On the partition that measured 374 MB per
+// layer in 263 us = 22 GB/s per CU, while a plain streaming loop on 64 CUs pulls 44-54 GB/s per workgroup (profiles/r02_bw_probe.txt A/A2):
+// the workgroups' life cycles, not the memory system, set the rate.  Here ONE resident workgroup per CU (4 waves, one per SIMD) WALKS the
+// items gridDim.x apart and keeps its memory pipe busy across them:
+//   * a wave's page (K 16 KiB | V 16 KiB, contiguous in the pool) arrives by LDS-DMA (global_load_lds, 32 x 1 KiB per wave, no registers,
+//     non-temporal) in the wave's own 32-KiB LDS buffer; the lane-linear fragment order of the pool makes the read-back one conflict-free
+//     ds_read_b128 per chunk into the MFMA A-operand registers;
+//   * as soon as a page is in registers the DMA of the NEXT item's page is issued into the same buffer, so it flies under this item's
+//     MFMAs, softmax, cross-wave combine and partial store; the next item's page id and q rows are fetched one item ahead as well;
+//   * items whose split lies past the row's last page are skipped by the (wave-uniform) walk: nothing is launched for them.
+// Arithmetic per item is that of decode_attn_kernel<4, true> statement for statement — same MFMA order, same softmax, same fixed-order
+// combine of the four waves, same partial layout — so the combine kernel and every bit downstream are unchanged (tests:
+// test_decode_kernels_gpu.py::test_decode_attention_stream_equals_per_split_bitwise, test_decode_plans_gpu.py).  Needs ONE (every wave
+// owns at most one page) and NW = 4; the launcher falls back to the kernel above otherwise.
+// LDS: 4 x 32 KiB page buffers | combine buffer [4][group][AT_LD] | m, l [4][16] each | pages, keys per row [64] each  (~142 KiB: one workgroup per CU)
+#ifndef ATTN_DMA_AUX
+#define ATTN_DMA_AUX 2      // cache policy bits of the DMA requests: 2 = nt (each KV byte is read once per step)
+#endif
+constexpr int ST_NW = 4, ST_PAGE_BYTES = 2 * PAGE_ELEMS * 2;
+
+__global__ __launch_bounds__(ST_NW * 64, 1) void decode_attn_stream_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
+                                                                          const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
+                                                                          int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                                          int B, int Hq, int Hkv, int n_splits, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
+    const int group = Hq / Hkv;
+    char* pagebuf = at_smem;                                                                  // [ST_NW][ST_PAGE_BYTES]
+    float* lds_o = reinterpret_cast<float*>(at_smem + ST_NW * ST_PAGE_BYTES);                 // [ST_NW][group][AT_LD]
+    float* lds_m = lds_o + ST_NW * group * AT_LD;                                             // [ST_NW][16]
+    float* lds_l = lds_m + ST_NW * 16;                                                        // [ST_NW][16]
+    int* lds_np = reinterpret_cast<int*>(lds_l + ST_NW * 16);                                 // [MAX_DECODE_ROWS] pages per row
+    int* lds_ctx = lds_np + MAX_DECODE_ROWS;                                                  // [MAX_DECODE_ROWS] keys per row
+    const int l = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = l & 15, g = l >> 4;
+    if ((int)threadIdx.x < B) {
+        const int c = ctx_len[threadIdx.x] + 1;                      // includes the token appended this step
+        lds_ctx[threadIdx.x] = c;
+        lds_np[threadIdx.x] = (c + PAGE - 1) / PAGE;
+    }
+    __syncthreads();
+    const int total = B * Hkv * n_splits, stride = gridDim.x, per_row = Hkv * n_splits;
+    // item -> (row, kv head, split); everything about an item is wave-uniform and kept in scalar registers (readfirstlane on what comes from LDS)
+    auto pages_of = [&](int row) { return __builtin_amdgcn_readfirstlane(lds_np[row]); };
+    auto next_active = [&](int it) {                                 // first item >= it on this workgroup's walk whose split owns a page
+        while (it < total && (it % n_splits) * ST_NW >= pages_of(it / per_row)) it += stride;
+        return it;
+    };
+    char* mybuf = pagebuf + w * ST_PAGE_BYTES;
+    // this wave's page of an item: page index split * 4 + w; its DMA is skipped (wave-uniform branch) when the row has no such page
+    auto load_page_id = [&](int it) {
+        const int row = it / per_row, pi = (it % n_splits) * ST_NW + w;
+        return __builtin_amdgcn_readfirstlane(block_table[(size_t)row * max_pages + min(pi, max_pages - 1)]);
+    };
+    // chunks [c0, c1) of the wave's page: 0-15 = K, 16-31 = V
+    auto issue_dma = [&](int it, int pg, int c0 = 0, int c1 = 32) {
+        const int row = it / per_row, pi = (it % n_splits) * ST_NW + w;
+        if (pi >= pages_of(row)) return;
+        const int hkv = (it / n_splits) % Hkv;
+        const bf16_t* src = pool + ((size_t)pg * Hkv + hkv) * 2 * PAGE_ELEMS + l * 8;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c >= c0 && c < c1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 512),
+                                                 (__attribute__((address_space(3))) void*)(mybuf + c * 1024), 16, 0, ATTN_DMA_AUX);
+    };
+    auto load_q = [&](int it, u32x4 (&qr)[4]) {
+        const int row = it / per_row, hkv = (it / n_splits) % Hkv;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qr[kk] = *reinterpret_cast<const u32x4*>(q + ((size_t)row * Hq + hkv * group + min(i, group - 1)) * 128 + kk * 32 + g * 8);
+    };
+
+    int it = next_active(blockIdx.x);
+    if (it >= total) return;
+    u32x4 qraw[4];
+    load_q(it, qraw);
+    issue_dma(it, load_page_id(it));
+    while (it < total) {
+        const int nxt = next_active(it + stride);
+        const int b = it / per_row, hkv = (it / n_splits) % Hkv, split = it % n_splits;
+        const int p = split * ST_NW + w;
+        const bool has_page = p < pages_of(b);
+        // the next item's small operands, one item ahead (clamped to a valid item when the walk is over: loaded, never used)
+        const int nx = nxt < total ? nxt : it;
+        u32x4 qnext[4];
+        const int pg_next = load_page_id(nx);
+        load_q(nx, qnext);
+        const int ctx = __builtin_amdgcn_readfirstlane(lds_ctx[b]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's page is in its LDS buffer (and everything requested above)
+        f32x4 o[8];
+#pragma unroll
+        for (int dg = 0; dg < 8; ++dg) o[dg] = f32x4{0, 0, 0, 0};
+        float m_run = -1e30f, l_run = 0.f;
+        if (has_page) {
+            bf16x8 kf[16], vf[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(mybuf + c * 1024 + l * 16);
+#ifdef ATTN_SPLIT_ISSUE      // experiment: the K half of the next page is requested as soon as this page's K half is in registers
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (nxt < total) issue_dma(nxt, pg_next, 0, 16);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int c = 0; c < 16; ++c) vf[c] = *reinterpret_cast<const bf16x8*>(mybuf + (16 + c) * 1024 + l * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the buffer is free: every fragment sits in registers
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef ATTN_SPLIT_ISSUE
+            if (nxt < total) issue_dma(nxt, pg_next, 16, 32);
+#else
+            if (nxt < total) issue_dma(nxt, pg_next);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 qf[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u32x4 z = {0, 0, 0, 0};
+                qf[kk] = __builtin_bit_cast(bf16x8, i < group ? qraw[kk] : z);
+            }
+            // ---- the arithmetic of decode_attn_kernel<4, true>::page_step(first = true), statement for statement
+            f32x4 s[4];
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                s[kg] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) s[kg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kg * 4 + kk], qf[kk], s[kg], 0, 0, 0);
+            }
+            const int key0 = p * PAGE;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kg * 16 + 4 * g + r;
+                    s[kg][r] = key < ctx ? s[kg][r] : -INFINITY;
+                    mx = fmaxf(mx, s[kg][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx * scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {
+                u32x4 pk;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float pv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[r] = __builtin_amdgcn_exp2f(fmaf(s[slab * 2 + t][r], scale_log2e, -m_new));
+                        psum += pv[r];
+                    }
+                    pk[t * 2] = pack_bf2(pv[0], pv[1]);
+                    pk[t * 2 + 1] = pack_bf2(pv[2], pv[3]);
+                }
+                pf[slab] = __builtin_bit_cast(bf16x8, pk);
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dg = 0; dg < 8; ++dg) o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dg], pf[0], o[dg], 0, 0, 0);
+#pragma unroll
+            for (int dg = 0; dg < 8; ++dg) o[dg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[8 + dg], pf[1], o[dg], 0, 0, 0);
+        } else if (nxt < total) {
+            issue_dma(nxt, pg_next);
+        }
+        // ---- wave partial -> LDS, fixed-order combine of the four waves, partial store (as in the per-split kernel)
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        if (g == 0) { lds_m[w * 16 + i] = m_run; lds_l[w * 16 + i] = l_run; }
+        if (i < group) {
+#pragma unroll
+            for (int dg = 0; dg < 8; ++dg) *reinterpret_cast<f32x4*>(lds_o + (w * group + i) * AT_LD + dg * 16 + 4 * g) = o[dg];
+        }
+        __syncthreads();
+        for (int item = threadIdx.x; item < group * 128; item += ST_NW * 64) {
+            const int j = item >> 7, d = item & 127;
+            float m = lds_m[j];
+#pragma unroll
+            for (int ww = 1; ww < ST_NW; ++ww) m = fmaxf(m, lds_m[ww * 16 + j]);
+            float acc = 0.f, lsum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < ST_NW; ++ww) {
+                const float f = __builtin_amdgcn_exp2f(lds_m[ww * 16 + j] - m);
+                acc += lds_o[(ww * group + j) * AT_LD + d] * f;
+                lsum += lds_l[ww * 16 + j] * f;
+            }
+            const size_t base = (((size_t)b * Hkv + hkv) * n_splits + split) * group + j;
+            part_o[base * 128 + d] = acc;
+            if (d == 0) { part_ml[base * 2] = m; part_ml[base * 2 + 1] = lsum; }
+        }
+        __syncthreads();                                             // the combine buffer is rewritten by the next item
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qraw[kk] = qnext[kk];
+        it = nxt;
+    }
+}
+
 // out[b][head*128 + d] = sum_s w_s O_s / sum_s w_s l_s   (grid (Hq, B), block 128).
 // ONE memory round trip: the context length, the (m, l) pairs and the first CMB_BATCH partial rows are all requested
 // up front, unconditionally (slots of splits without pages hold stale data and are masked with a select, never
@@ -514,13 +716,49 @@ int decode_attn_splits(int max_seq_len) {
     return std::max(1, std::min((pages + nw - 1) / nw, 64));
 }
 
+// Which decode-attention kernel runs (process-wide; both produce the same bits): the per-split kernel, or — when every resident workgroup
+// would get at least `min` items — the streaming kernel with one workgroup per CU.  part_cus > 0: the stream is CU-masked to that many CUs.
+// stream_mode: 1 = the streaming kernel wherever it is legal, 0 = never, -1 = by the bound above (DOTS_OCR_ATTN_STREAM=0 / 1 sets the process
+// default of that case; DOTS_OCR_ATTN_STREAM_MIN overrides the items-per-CU bound).
+int decode_attn_stream_wgs(int B, int Hkv, int n_splits, int max_pages, int part_cus, int stream_mode) {
+    static const int env_mode = [] { const char* e = getenv("DOTS_OCR_ATTN_STREAM"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const int mode = stream_mode >= 0 ? stream_mode : env_mode;
+    static const int min_items = [] { const char* e = getenv("DOTS_OCR_ATTN_STREAM_MIN"); return e ? std::max(1, atoi(e)) : 6; }();
+    if (mode == 0 || decode_attn_waves() != ST_NW || (int64_t)n_splits * ST_NW < max_pages || B > MAX_DECODE_ROWS) return 0;
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
+        n_cus = v;
+    }
+    const int cus = part_cus > 0 ? std::min(part_cus, n_cus) : n_cus, items = B * Hkv * n_splits;
+    if (mode == 1) return std::min(cus, items);
+    return items >= min_items * cus ? cus : 0;
+}
+
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
-                              int B, int Hq, int Hkv, int n_splits, float scale) {
+                              int B, int Hq, int Hkv, int n_splits, float scale, int part_cus, int stream_mode) {
     if (Hq % Hkv != 0 || Hq / Hkv > 16) return hipErrorInvalidValue;
     const float sl = scale * 1.44269504088896340736f;
-    const dim3 grid(n_splits, Hkv, B);
     const int nw = decode_attn_waves(), group = Hq / Hkv;
+    if (const int wgs = decode_attn_stream_wgs(B, Hkv, n_splits, max_pages, part_cus, stream_mode)) {
+        static uint32_t attr = 0;
+        const size_t lds_s = (size_t)ST_NW * ST_PAGE_BYTES + ((size_t)ST_NW * group * AT_LD + 2 * ST_NW * 16) * sizeof(float) + 2 * MAX_DECODE_ROWS * sizeof(int);
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint32_t bit = 1u << (dev & 31);
+        if (!(__atomic_load_n(&attr, __ATOMIC_ACQUIRE) & bit)) {            // dynamic LDS above 64 KiB: opted into once per device
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            if (e != hipSuccess) return e;
+            __atomic_fetch_or(&attr, bit, __ATOMIC_RELEASE);
+        }
+        hipLaunchKernelGGL(decode_attn_stream_kernel, dim3(wgs), dim3(ST_NW * 64), lds_s, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml,
+                           B, Hq, Hkv, n_splits, sl);
+        return hipGetLastError();
+    }
+    const dim3 grid(n_splits, Hkv, B);
     const size_t lds = ((size_t)nw * group * AT_LD + 2 * nw * 16) * sizeof(float);
     const bool one = (int64_t)n_splits * nw >= max_pages;        // every wave owns at most one page: the light-weight instantiation
 #define ATTN_GO(NWV, ONEV) hipLaunchKernelGGL((decode_attn_kernel<NWV, ONEV>), grid, dim3(NWV * 64), lds, s, q, pool_layer, ctx_len, block_table, max_pages, part_o, part_ml, Hq, Hkv, n_splits, sl)

@@ -180,6 +180,7 @@ struct DotsEngine {
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     // decode launch plan forced on every step (dots_set_decode_plan): 0 = by stream (whole chip / CU partition), 1 = always the partition plan
     int force_part = 0;
+    int attn_stream = -1;                  // decode attention kernel (dots_set_decode_plan bits 1-2): -1 = by items per CU, 1 = streaming wherever legal, 0 = per split
     int B = 0;                             // sequences of the current batch
     int B_sel = 0;                         // rows the token-selection kernel runs over
     // ---- continuous batching: every sequence slot b < max_batch is free or occupied; the decode graph runs over rows
@@ -554,7 +555,11 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_logits, (size_t)mb * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
-    if (const char* fm = getenv("DOTS_OCR_DECODE_PLAN")) e->force_part = atoi(fm) ? 1 : 0;
+    if (const char* fm = getenv("DOTS_OCR_DECODE_PLAN")) {
+        const int plan = atoi(fm);
+        e->force_part = plan & 1;
+        e->attn_stream = (plan & 2) ? 1 : (plan & 4) ? 0 : -1;
+    }
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
     // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
     e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
@@ -1004,7 +1009,7 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
                           Hkv, c.rms_norm_eps, part));
-        CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale));
+        CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale, part ? e->dec_cus : 0, e->attn_stream));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
         CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part));
         CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0));
@@ -1598,9 +1603,12 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
 
 int dots_set_decode_plan(DotsEngine* e, int plan) {
     if (!e) return DOTS_E_INVALID;
-    if (plan < 0 || plan > 1) return e->fail(DOTS_E_INVALID, "decode plan must be 0 (by stream) or 1 (partition plan on every step)");
-    if (plan != e->force_part) {
-        e->force_part = plan;
+    if (plan < 0 || plan > 5 || (plan & 6) == 6)
+        return e->fail(DOTS_E_INVALID, "decode plan must be 0 (by stream) or 1 (partition plan on every step), + 2 (streaming attention) or + 4 (per-split attention)");
+    const int part = plan & 1, stream = (plan & 2) ? 1 : (plan & 4) ? 0 : -1;
+    if (part != e->force_part || stream != e->attn_stream) {
+        e->force_part = part;
+        e->attn_stream = stream;
         drop_step_graphs(e);                               // the captured decode steps bake the launch plan in
     }
     return DOTS_OK;
@@ -1863,7 +1871,7 @@ int dots_op_decode_attn(DotsEngine* e, const void* q, const void* pool_layer, co
     CK(hipMemsetAsync(po, 0xff, rb * Hq * n_splits * 128 * 4, e->stream));      // NaN: a partial read without having been written shows up
     CK(hipMemsetAsync(pml, 0xff, rb * Hq * n_splits * 2 * 4, e->stream));
     CK(launch_decode_attn(e->stream, (const bf16_t*)q, (const bf16_t*)pool_layer, ctx_len_dev, block_table_dev, max_pages, po, pml, B, Hq, Hkv, n_splits,
-                          1.0f / sqrtf(128.0f)));
+                          1.0f / sqrtf(128.0f), e->force_part ? e->dec_cus : 0, e->attn_stream));      // dots_set_decode_plan: the plan's kernel choice
     CK(launch_decode_attn_combine(e->stream, po, pml, ctx_len_dev, att, B, Hq, Hkv, n_splits));
     CK(launch_unpack_x(e->stream, att, (bf16_t*)out, B, Hq * 128));
     CK(hipStreamSynchronize(e->stream));

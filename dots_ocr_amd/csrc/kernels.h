@@ -65,7 +65,10 @@ int decode_attn_waves();                       // pages in flight per decode-att
 int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,
                               const int32_t* block_table, int max_pages, float* part_o, float* part_ml,
-                              int B, int Hq, int Hkv, int n_splits, float scale);
+                              int B, int Hq, int Hkv, int n_splits, float scale, int part_cus = 0, int stream_mode = -1);
+// > 0: launch_decode_attn runs the streaming kernel (round 5) with that many resident workgroups; 0: one workgroup per (row, kv head, split).
+// part_cus > 0: the stream is CU-masked to that many CUs; stream_mode 1 / 0 / -1 = always where legal / never / by items per CU
+int decode_attn_stream_wgs(int B, int Hkv, int n_splits, int max_pages, int part_cus, int stream_mode = -1);
 hipError_t launch_decode_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, const int32_t* ctx_len, bf16_t* out,
                                       int B, int Hq, int Hkv, int n_splits);
 // Per-step token bookkeeping state (device pointers), shared by the arg-max and the sampling kernels.

@@ -314,7 +314,8 @@ class Engine:
 
     def set_decode_plan(self, plan: int):
         """0 = launch plan by stream (whole chip / CU partition beside a prefetched tower), 1 = the partition plan (whole-tile projections,
-        pair-walking gate|up) on every step; bit-identical results."""
+        pair-walking gate|up) on every step; + 2 = streaming decode attention wherever legal, + 4 = per-split decode attention (default: by
+        items per CU); bit-identical results."""
         self._ck(self.lib.dots_set_decode_plan(self.h, int(plan)), "dots_set_decode_plan")
 
     def set_gemm_plan(self, plan: int):

@@ -162,7 +162,10 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
  * whole-chip plan (qkv / o_proj / down_proj as 8-row half tiles: 256 / 192 / 192 workgroups; one gate|up workgroup per tile pair), or —
  * while the step is replayed on the decode CU partition beside a prefetched vision tower (dots_vit_prefetch) — the PARTITION plan: the
  * projections as whole 16-row tiles (half as many workgroups) and gate|up as one resident round of workgroups that walk the tile pairs.
- * 1 = the partition plan on every step (tests, A/B runs; slower on the whole chip).  Environment DOTS_OCR_DECODE_PLAN sets the default. */
+ * 1 = the partition plan on every step (tests, A/B runs; slower on the whole chip).  Environment DOTS_OCR_DECODE_PLAN sets the default.
+ * Round 5: + 2 = the STREAMING decode-attention kernel (one resident workgroup per CU walks the (row, kv head, split) items, pages arrive by
+ * LDS-DMA one item ahead) wherever it is legal, + 4 = always one workgroup per item; neither bit = streaming when every CU of the stream
+ * gets at least 6 items (the 64-row step of the pipelined bench).  Same bits either way. */
 int dots_set_decode_plan(DotsEngine* e, int plan);
 /* Launch plan of the 256-wide bf16 MFMA GEMM behind the vision tower and the prefill (results are bit-identical under either plan:
  * the same MFMAs in the same k order per output element).  0 = 8 waves per workgroup, two per SIMD running half a K sub-tile apart

@@ -149,8 +149,10 @@ def test_dec_qkv_without_bias(eng):
 
 
 # ------------------------------------------------------------------------------------------------ decode attention
-def _attn_case(eng, ctxs, max_seq_len, seed, spike=False):
-    """ctxs[b] = tokens already cached; the step attends over ctx + 1 keys (the appended token included)."""
+def _attn_case(eng, ctxs, max_seq_len, seed, spike=False, plans=(None,)):
+    """ctxs[b] = tokens already cached; the step attends over ctx + 1 keys (the appended token included).
+    plans: dots_set_decode_plan values to run the kernel under (None = leave the engine as it is); every plan is held to the oracle and all
+    plans to each other BIT FOR BIT (the streaming kernel of round 5 against the per-split kernel)."""
     B = len(ctxs)
     g = torch.Generator().manual_seed(seed)
     max_pages = (max_seq_len + 63) // 64
@@ -175,13 +177,24 @@ def _attn_case(eng, ctxs, max_seq_len, seed, spike=False):
         ref = om._attention(q[b].float().unsqueeze(1), K.float().transpose(0, 1).repeat_interleave(rep, 0),
                             Vv.float().transpose(0, 1).repeat_interleave(rep, 0), 1 / math.sqrt(128), False, True)[:, 0]
         refs.append(ref)
-    out = torch.zeros(B, HQ * 128, dtype=torch.bfloat16, device="cuda")
     qd, pd, cd, td = dev(q.reshape(B, HQ * 128)), dev(pool), dev(torch.tensor(ctxs, dtype=torch.int32)), dev(table)
-    torch.cuda.synchronize()
-    eng.op_decode_attn(qd.data_ptr(), pd.data_ptr(), cd.data_ptr(), td.data_ptr(), max_pages, out.data_ptr(), B, HQ, HKV, max_seq_len)
-    got = out.view(B, HQ, 128).float().cpu()
-    for b in range(B):
-        close(got[b], refs[b], rel=2 ** -6, abs_=4e-3, what=f"seq {b} ctx {ctxs[b]}")
+    outs = []
+    try:
+        for plan in plans:
+            if plan is not None:
+                eng.set_decode_plan(plan)
+            out = torch.zeros(B, HQ * 128, dtype=torch.bfloat16, device="cuda")
+            torch.cuda.synchronize()
+            eng.op_decode_attn(qd.data_ptr(), pd.data_ptr(), cd.data_ptr(), td.data_ptr(), max_pages, out.data_ptr(), B, HQ, HKV, max_seq_len)
+            got = out.view(B, HQ, 128).float().cpu()
+            for b in range(B):
+                close(got[b], refs[b], rel=2 ** -6, abs_=4e-3, what=f"plan {plan} seq {b} ctx {ctxs[b]}")
+            outs.append(out.cpu().view(torch.int16))
+    finally:
+        if any(pl is not None for pl in plans):
+            eng.set_decode_plan(0)
+    for plan, o in zip(plans[1:], outs[1:]):
+        assert torch.equal(o, outs[0]), f"decode attention under plan {plan} differs from plan {plans[0]} in {int((o != outs[0]).sum())} elements"
 
 
 @pytest.mark.parametrize("ctxs,max_seq_len", [
@@ -196,6 +209,25 @@ def _attn_case(eng, ctxs, max_seq_len, seed, spike=False):
 ])
 def test_decode_attention_matches_oracle(eng, ctxs, max_seq_len):
     _attn_case(eng, ctxs, max_seq_len, seed=sum(ctxs) + len(ctxs))
+
+
+@pytest.mark.parametrize("ctxs,max_seq_len", [
+    ([0], 64),                                                   # one item, one wave with a page
+    ([1, 63, 64, 65, 0, 127, 128, 255], 640),                    # page edges: waves without a page inside an active split
+    ([5200] * 8, 6224),                                          # the bench's rows
+    ([1, 63, 64, 65, 5200, 6223, 5199, 300], 6224),              # ragged: most splits of the short rows are skipped by the walk
+    ([5150 + (37 * i) % 1000 for i in range(64)], 6288),         # the pipelined step: 64 rows x 25 splits = 3200 items on the resident workgroups
+    ([(613 * i) % 1500 + 1 for i in range(21)], 1600),           # B = 21: the combine writes two X-image tiles
+    ([16383, 64, 9000], 16384),                                  # 64 splits x 4 waves = 256 pages: the largest capacity the one-page-per-wave plan covers
+])
+def test_decode_attention_stream_equals_per_split_bitwise(eng, ctxs, max_seq_len):
+    """Round 5: the streaming kernel (one resident workgroup per CU walking the items, pages by LDS-DMA one item ahead) against the per-split
+    kernel: plan 4 = per split, 2 = streaming on the whole chip, 3 = streaming on the partition plan's workgroup count.  Same bits."""
+    _attn_case(eng, ctxs, max_seq_len, seed=sum(ctxs) + len(ctxs), plans=(4, 2, 3))
+
+
+def test_decode_attention_spiked_key_stream(eng):
+    _attn_case(eng, [5200, 777, 6000], 6224, seed=5, spike=True, plans=(4, 2))
 
 
 def test_decode_attention_dominant_late_key(eng):

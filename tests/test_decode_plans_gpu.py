@@ -78,6 +78,27 @@ def test_plans_under_graph_replay_and_generate(tiny):
         assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
+@pytest.mark.parametrize("lens", [[63, 64, 65, 1, 127, 128, 200, 190], [5, 300, 61]])
+def test_streaming_attention_plans_bitwise(tiny, lens):
+    """Round 5: + 2 forces the streaming decode-attention kernel, + 4 the per-split one; logits of every step bit for bit, on the whole-chip
+    plan (4 vs 2) and on the partition plan (5 vs 3), eager steps and graph replay."""
+    cfg, sd, eng = tiny
+    ids, ln = _prompts(cfg, lens, seed=len(lens))
+    try:
+        ref = _decode(eng, 4, ids, ln, 6)
+        _assert_same(ref, _decode(eng, 2, ids, ln, 6), f"streaming attention, prompt lengths {lens}")
+        _assert_same(ref, _decode(eng, 3, ids, ln, 6), f"streaming attention on the partition plan, prompt lengths {lens}")
+        _assert_same(ref, _decode(eng, 5, ids, ln, 6), f"per-split attention on the partition plan, prompt lengths {lens}")
+        eng.set_decode_plan(4)
+        a = eng.generate(ids, ln, max_new_tokens=70)
+        eng.set_decode_plan(2)
+        b = eng.generate(ids, ln, max_new_tokens=70)
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    finally:
+        eng.set_decode_plan(0)
+
+
 def test_batch_of_nine(tiny):
     cfg, sd, eng = tiny
     ids, ln = _prompts(cfg, [20 + 3 * i for i in range(9)], seed=2)
@@ -141,4 +162,6 @@ def test_plans_at_the_real_dimensions_bitwise():
     ids, ln = _prompts(cfg, lens, seed=3)
     ref = _decode(eng, 0, ids, ln, 5)
     _assert_same(ref, _decode(eng, 1, ids, ln, 5), "real dimensions, partition plan")
+    _assert_same(ref, _decode(eng, 3, ids, ln, 5), "real dimensions, partition plan with the streaming attention kernel (round 5)")
+    _assert_same(ref, _decode(eng, 6 - 2, ids, ln, 5), "real dimensions, per-split attention forced")
     eng.close()

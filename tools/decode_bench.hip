@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
 #endif
     const int max_pages = (max_seq + 63) / 64;
     const int n_splits = decode_attn_splits(max_seq);
+    const int R = std::max(16, (B + 15) / 16 * 16);          // rows the buffers hold (round 5: up to 64 rows = the pipelined step's batch)
     // weights: 0x3c3c = bf16 0.0115.  DOTS_BENCH_FP8=1: the e4m3 instantiations (1 byte per weight, 0x3c = 1.5; scales 0x3c3c3c3c = 0.0115)
     const bool fp8 = getenv("DOTS_BENCH_FP8") != nullptr;
     const size_t wb = fp8 ? 1 : 2;
@@ -111,16 +112,16 @@ int main(int argc, char** argv) {
     bf16_t* fnorm = dalloc<bf16_t>(H, 0x3f);
     const size_t pool_layer = (size_t)B * max_pages * Hkv * 2 * 8192;
     bf16_t* pool = dalloc<bf16_t>(pool_layer * L, 0x3c);
-    std::vector<int32_t> h_tab((size_t)16 * max_pages), h_ctx(16, ctx);
-    for (int b = 0; b < 16; ++b) for (int p = 0; p < max_pages; ++p) h_tab[(size_t)b * max_pages + p] = (b % B) * max_pages + p;
-    int32_t *tab = dalloc<int32_t>(h_tab.size()), *ctx_len = dalloc<int32_t>(16), *cur = dalloc<int32_t>(16), *out_ids = dalloc<int32_t>(16 * 64),
-            *out_lens = dalloc<int32_t>(16), *fin = dalloc<int32_t>(16), *am_idx = dalloc<int32_t>(16 * 64);
+    std::vector<int32_t> h_tab((size_t)R * max_pages), h_ctx(R, ctx);
+    for (int b = 0; b < R; ++b) for (int p = 0; p < max_pages; ++p) h_tab[(size_t)b * max_pages + p] = (b % B) * max_pages + p;
+    int32_t *tab = dalloc<int32_t>(h_tab.size()), *ctx_len = dalloc<int32_t>(R), *cur = dalloc<int32_t>(R), *out_ids = dalloc<int32_t>(R * 64),
+            *out_lens = dalloc<int32_t>(R), *fin = dalloc<int32_t>(R), *am_idx = dalloc<int32_t>(R * 64);
     CK(hipMemcpy(tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(ctx_len, h_ctx.data(), 64, hipMemcpyHostToDevice));
-    float* am_val = dalloc<float>(16 * 64);
-    bf16_t *h0 = dalloc<bf16_t>(16 * H, 0x3c), *h1 = dalloc<bf16_t>(16 * H, 0x3c), *dq = dalloc<bf16_t>(16 * Nq), *att = dalloc<bf16_t>(16 * Nq), *act = dalloc<bf16_t>((size_t)16 * I);
-    float *slabs = dalloc<float>((size_t)4 * 16 * H), *po = dalloc<float>((size_t)16 * Hq * 64 * 128), *pml = dalloc<float>((size_t)16 * Hq * 64 * 2),
-          *logits = dalloc<float>((size_t)16 * V);
+    CK(hipMemcpy(ctx_len, h_ctx.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+    float* am_val = dalloc<float>(R * 64);
+    bf16_t *h0 = dalloc<bf16_t>((size_t)R * H, 0x3c), *h1 = dalloc<bf16_t>((size_t)R * H, 0x3c), *dq = dalloc<bf16_t>((size_t)R * Nq), *att = dalloc<bf16_t>((size_t)R * Nq), *act = dalloc<bf16_t>((size_t)R * I);
+    float *slabs = dalloc<float>((size_t)4 * R * H), *po = dalloc<float>((size_t)R * Hq * 64 * 128), *pml = dalloc<float>((size_t)R * Hq * 64 * 2),
+          *logits = dalloc<float>((size_t)R * V);
     std::vector<float> f(64);
     for (int i = 0; i < 64; ++i) f[i] = 1.0f / powf(1e6f, (float)(2 * i) / 128.0f);
     float* inv_freq = dalloc<float>(64);
@@ -132,11 +133,12 @@ int main(int argc, char** argv) {
     st.max_len = nullptr; st.n_eos = 0; st.out_stride = 64; st.cap = 1; st.advance_ctx = 0;       // cap 1: rows finish at once, ctx stays put
 
     const int full = getenv("DOTS_BENCH_FULL") ? 1 : 0;      // whole-tile projections (the half-chip launch plan)
+    const int part_cus = full ? (getenv("DOTS_BENCH_CUS") ? atoi(getenv("DOTS_BENCH_CUS")) : 128) : 0;      // the partition plan caps gate|up's grid at what the partition holds
+    printf("decode attention: %s\n", decode_attn_stream_wgs(B, Hkv, n_splits, max_pages, part_cus) ? "streaming kernel (one resident workgroup per CU)" : "one workgroup per (row, kv head, split)");
     auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, full)); };
-    auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale)); };
+    auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale, part_cus)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
     auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, full)); };
-    const int part_cus = full ? (getenv("DOTS_BENCH_CUS") ? atoi(getenv("DOTS_BENCH_CUS")) : 128) : 0;      // the partition plan caps gate|up's grid at what the partition holds
     auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus)); };
     auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I, full)); };
     auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps)); };
