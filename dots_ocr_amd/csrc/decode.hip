@@ -716,14 +716,17 @@ int decode_attn_splits(int max_seq_len) {
     return std::max(1, std::min((pages + nw - 1) / nw, 64));
 }
 
-// Which decode-attention kernel runs (process-wide; both produce the same bits): the per-split kernel, or — when every resident workgroup
-// would get at least `min` items — the streaming kernel with one workgroup per CU.  part_cus > 0: the stream is CU-masked to that many CUs.
-// stream_mode: 1 = the streaming kernel wherever it is legal, 0 = never, -1 = by the bound above (DOTS_OCR_ATTN_STREAM=0 / 1 sets the process
-// default of that case; DOTS_OCR_ATTN_STREAM_MIN overrides the items-per-CU bound).
+// Which decode-attention kernel runs (process-wide; both produce the same bits): the per-split kernel (default), or the streaming kernel
+// with one workgroup per CU.  MEASURED (profiles/r05_decode_attn_stream_ab.txt): the streaming kernel is the slower one everywhere — 237 vs
+// 120 us per launch at 64 rows on the 64-CU partition, 85 vs 63 us on the whole chip, 15.3 vs 11.2 us at 8 rows — one 32-KiB page in flight
+// per wave is less memory parallelism than the 3-4 co-resident short-lived workgroups of the per-split kernel, whatever their life cycle
+// costs; requesting the K half early or allocating DMA changed nothing.  It therefore never runs by default: opt-in only.
+// part_cus > 0: the stream is CU-masked to that many CUs.  stream_mode: 1 = the streaming kernel wherever it is legal, 0 = never, -1 = the
+// process default (DOTS_OCR_ATTN_STREAM=1: wherever legal; DOTS_OCR_ATTN_STREAM_MIN=n: from n items per CU; unset: never).
 int decode_attn_stream_wgs(int B, int Hkv, int n_splits, int max_pages, int part_cus, int stream_mode) {
     static const int env_mode = [] { const char* e = getenv("DOTS_OCR_ATTN_STREAM"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    const int mode = stream_mode >= 0 ? stream_mode : env_mode;
-    static const int min_items = [] { const char* e = getenv("DOTS_OCR_ATTN_STREAM_MIN"); return e ? std::max(1, atoi(e)) : 6; }();
+    static const int min_items = [] { const char* e = getenv("DOTS_OCR_ATTN_STREAM_MIN"); return e ? std::max(1, atoi(e)) : 0; }();
+    const int mode = stream_mode >= 0 ? stream_mode : (env_mode >= 0 ? env_mode : (min_items > 0 ? -1 : 0));
     if (mode == 0 || decode_attn_waves() != ST_NW || (int64_t)n_splits * ST_NW < max_pages || B > MAX_DECODE_ROWS) return 0;
     static int n_cus = 0;
     if (n_cus == 0) {

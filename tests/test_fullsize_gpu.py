@@ -73,8 +73,8 @@ def _flash_packed(eng, qs, ks, vs):
     lens = [q.shape[0] for q in qs]
     T = sum(lens)
     qd = torch.cat(qs).permute(1, 0, 2).contiguous()
-    kd = torch.zeros(H, T + 64, 128, dtype=torch.bfloat16, device="cuda")
-    kd[:, :T] = torch.cat(ks).permute(1, 0, 2)
+    kd = torch.zeros(H * T + 64, 128, dtype=torch.bfloat16, device="cuda")          # head stride T (the engine's layout) + the 64 spare rows
+    kd[:H * T] = torch.cat(ks).permute(1, 0, 2).reshape(H * T, 128)
     vt = torch.cat([_vt(v) for v in vs], dim=2).contiguous()
     out = torch.zeros(T, H * 128, dtype=torch.bfloat16, device="cuda")
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
