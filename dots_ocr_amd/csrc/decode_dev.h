@@ -50,9 +50,11 @@ DEVI void pin_rows(const Rows<MAXR, NC>& R) {
     for (int c = 0; c < NC; ++c) PIN(R.w[c]);
 }
 
-// one row -> rmsnorm -> LDS image; ~12 VALU per bf16 pair (packed fp32 multiplies, v_cvt_pk_bf16_f32 roundings)
+// RMS statistic of one row held as NC 16-B chunks per lane (chunk c of lane l = elements c * 512 + 8 l .. + 7) -> 1 / rms.  ONE definition for
+// every kernel that normalises a residual row (the LDS-image prologues below and the wide kernels of decode_fused.hip, which need the
+// statistic only): the bits of a normalised row must not depend on the kernel that produced them.
 template <int NC>
-DEVI void row_norm_to_lds(const u32x4 (&v)[NC], const u32x4 (&w)[NC], int r, int dim, float eps, bf16_t* __restrict__ xs, int XR, int lane) {
+DEVI float row_rstd(const u32x4 (&v)[NC], int dim, float eps, int lane) {
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -64,19 +66,31 @@ DEVI void row_norm_to_lds(const u32x4 (&v)[NC], const u32x4 (&w)[NC], int r, int
         }
         ss += (c * 512 + lane * 8 < dim) ? pc : 0.f;              // clamped (repeated) chunks past the row end do not count
     }
-    const float rstd = rsqrtf(wave_sum(ss) / dim + eps);
+    return rsqrtf(wave_sum(ss) / dim + eps);
+}
+
+// 8 consecutive elements of a row: bf16(bf16(x * rstd) * w)   (modeling_qwen2.py:246-252: normalise in fp32, cast, then * weight)
+DEVI u32x4 norm8(const u32x4 v, const u32x4 w, float rstd) {
     const f32x2 rs2 = {rstd, rstd};
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f32x2 x = f32x2{lo_bf(v[e]), hi_bf(v[e])} * rs2;
+        const uint32_t t = pack_bf2(x[0], x[1]);
+        const f32x2 y = f32x2{lo_bf(t), hi_bf(t)} * f32x2{lo_bf(w[e]), hi_bf(w[e])};
+        o[e] = pack_bf2(y[0], y[1]);
+    }
+    return o;
+}
+
+// one row -> rmsnorm -> LDS image; ~12 VALU per bf16 pair (packed fp32 multiplies, v_cvt_pk_bf16_f32 roundings)
+template <int NC>
+DEVI void row_norm_to_lds(const u32x4 (&v)[NC], const u32x4 (&w)[NC], int r, int dim, float eps, bf16_t* __restrict__ xs, int XR, int lane) {
+    const float rstd = row_rstd<NC>(v, dim, eps, lane);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int k = c * 512 + lane * 8;
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x2 x = f32x2{lo_bf(v[c][e]), hi_bf(v[c][e])} * rs2;
-            const uint32_t t = pack_bf2(x[0], x[1]);                   // modeling_qwen2.py:246-252: normalise in fp32, cast, then * weight
-            const f32x2 y = f32x2{lo_bf(t), hi_bf(t)} * f32x2{lo_bf(w[c][e]), hi_bf(w[c][e])};
-            o[e] = pack_bf2(y[0], y[1]);
-        }
+        const u32x4 o = norm8(v[c], w[c], rstd);
         if (k < dim) *reinterpret_cast<u32x4*>(xs + ((size_t)(k >> 3) * XR + r) * 8) = o;
     }
 }

@@ -52,6 +52,43 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restric
         *reinterpret_cast<u32x4*>(h + (size_t)b * dim + k) = *reinterpret_cast<const u32x4*>(src + k);
 }
 
+// ---- epilogue of one lane of the qkv projection: x = D[row 4g + r][batch row] (split-K reduced) -> scale, bias, bf16 rounding of the qkv
+// tensor, RoPE, q store / K, V page append.  f0 = the lane's first feature (q / k heads: rows = features (f0, f0 + 64, f0 + 1, f0 + 65); v
+// heads: f0 .. f0 + 3), row = the batch row, pos / page = its position and the page that holds it.  Shared by dec_qkv_kernel and
+// dec_qkv_wide_kernel: one definition, the same bits.
+template <typename WT>
+DEVI void qkv_epilogue(f32x4 x, bool rot, int head, int Hq, int Hkv, int f0, bool has_bias, uint32_t bia0, uint32_t bia1, f32x2 sc0, f32x2 sc1,
+                       const float (&rc)[2], const float (&rs)[2], int pos, int page, int row, bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out) {
+#pragma clang fp contract(off)      // every fused multiply-add below is written out: the bits must not depend on the kernel this is inlined into
+    const int key = pos & 63;
+    // bias of rows r = 0..3: rot (lo(bia0), lo(bia1), hi(bia0), hi(bia1)), else (lo(bia0), hi(bia0), lo(bia1), hi(bia1))
+    const float b0 = has_bias ? lo_bf(bia0) : 0.f, b1 = has_bias ? (rot ? lo_bf(bia1) : hi_bf(bia0)) : 0.f;
+    const float b2 = has_bias ? (rot ? hi_bf(bia0) : lo_bf(bia1)) : 0.f, b3 = has_bias ? hi_bf(bia1) : 0.f;
+    if constexpr (is_fp8<WT>::value) {
+        x[0] *= sc0[0]; x[1] *= rot ? sc1[0] : sc0[1]; x[2] *= rot ? sc0[1] : sc1[0]; x[3] *= sc1[1];
+    }
+    const float y[4] = {bf2f(f2bf(x[0] + b0)), bf2f(f2bf(x[1] + b1)), bf2f(f2bf(x[2] + b2)), bf2f(f2bf(x[3] + b3))};   // the qkv output is a bf16 tensor
+    if (rot) {
+        // pairs (y0, y1) = features (d, d + 64) and (y2, y3) = (d + 1, d + 65)
+        const int d = f0;
+        const uint32_t lo = pack_bf2(__builtin_fmaf(y[0], rc[0], -(y[1] * rs[0])), __builtin_fmaf(y[2], rc[1], -(y[3] * rs[1])));     // features d, d + 1
+        const uint32_t hi = pack_bf2(__builtin_fmaf(y[1], rc[0], y[0] * rs[0]), __builtin_fmaf(y[3], rc[1], y[2] * rs[1]));           // features d + 64, d + 65
+        if (head < Hq) {
+            bf16_t* qp = q_out + ((size_t)row * Hq + head) * 128;
+            *reinterpret_cast<uint32_t*>(qp + d) = lo;
+            *reinterpret_cast<uint32_t*>(qp + d + 64) = hi;
+        } else {
+            bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
+            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d) * 8 + (d & 7)) = lo;
+            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d + 64) * 8 + (d & 7)) = hi;
+        }
+    } else {
+        bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vp[v_off(key, f0 + r)] = f2bf(y[r]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // grid = (Hq + 2 Hkv) * 16 workgroups (one 8-row HALF tile each: 256 at dots.ocr's 12 + 2 + 2 heads) x 16 waves (K-slices).
 // The rows of a q / k head are stored PERMUTED (launch_pack_frag_qkv): tile j of a head holds features 8j .. 8j+7
@@ -133,35 +170,18 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     f32x4 x = {0, 0, 0, 0};
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) x += red[sl * 64 + lane];
-    // ---- 5. epilogue: D[row 4g + r][batch m]
-    const int key = pos & 63;
-    // bias of rows r = 0..3: rot (lo(bia0), lo(bia1), hi(bia0), hi(bia1)), else (lo(bia0), hi(bia0), lo(bia1), hi(bia1))
-    const float b0 = bias ? lo_bf(bia0) : 0.f, b1 = bias ? (rot ? lo_bf(bia1) : hi_bf(bia0)) : 0.f;
-    const float b2 = bias ? (rot ? hi_bf(bia0) : lo_bf(bia1)) : 0.f, b3 = bias ? hi_bf(bia1) : 0.f;
-    if constexpr (is_fp8<WT>::value) {
-        x[0] *= sc0[0]; x[1] *= rot ? sc1[0] : sc0[1]; x[2] *= rot ? sc0[1] : sc1[0]; x[3] *= sc1[1];
-    }
-    const float y[4] = {bf2f(f2bf(x[0] + b0)), bf2f(f2bf(x[1] + b1)), bf2f(f2bf(x[2] + b2)), bf2f(f2bf(x[3] + b3))};   // the qkv output is a bf16 tensor
-    if (rot) {
-        // pairs (y0, y1) = features (d, d + 64) and (y2, y3) = (d + 1, d + 65)
-        const int d = f0;
-        const uint32_t lo = pack_bf2(y[0] * rc[0] - y[1] * rs[0], y[2] * rc[1] - y[3] * rs[1]);     // features d, d + 1
-        const uint32_t hi = pack_bf2(y[1] * rc[0] + y[0] * rs[0], y[3] * rc[1] + y[2] * rs[1]);     // features d + 64, d + 65
-        if (head < Hq) {
-            bf16_t* qp = q_out + ((size_t)m * Hq + head) * 128;
-            *reinterpret_cast<uint32_t*>(qp + d) = lo;
-            *reinterpret_cast<uint32_t*>(qp + d + 64) = hi;
-        } else {
-            bf16_t* kp = pool + ((size_t)(page * Hkv + (head - Hq)) * 2) * PAGE_ELEMS;
-            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d) * 8 + (d & 7)) = lo;
-            *reinterpret_cast<uint32_t*>(kp + k_chunk(key, d + 64) * 8 + (d & 7)) = hi;
-        }
-    } else {
-        bf16_t* vp = pool + ((size_t)(page * Hkv + (head - Hq - Hkv)) * 2 + 1) * PAGE_ELEMS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vp[v_off(key, f0 + r)] = f2bf(y[r]);
-    }
+    qkv_epilogue<WT>(x, rot, head, Hq, Hkv, f0, bias != nullptr, bia0, bia1, sc0, sc1, rc, rs, pos, page, m, pool, q_out);
     TRACE(6);
+}
+
+// ---- residual epilogue of one lane of a projection: h[row][col0 .. col0 + 3] = bf16(residual + sum * scale).  One definition for the
+// projection kernels (a row's bits must not depend on the batch it shares, i.e. on which of them ran).
+template <typename WT>
+DEVI void proj_epilogue(bf16_t* __restrict__ hp, u32x2 res, f32x4 s, f32x4 sc) {
+#pragma clang fp contract(off)
+    if constexpr (is_fp8<WT>::value) s *= sc;
+    const u32x2 o = {pack_bf2(lo_bf(res[0]) + s[0], hi_bf(res[0]) + s[1]), pack_bf2(lo_bf(res[1]) + s[2], hi_bf(res[1]) + s[3])};
+    *reinterpret_cast<u32x2*>(hp) = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,9 +253,7 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
     f32x4 s = {0, 0, 0, 0};
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) s += red[sl * 64 + lane];
-    if constexpr (is_fp8<WT>::value) s *= sc;
-    const u32x2 o = {pack_bf2(lo_bf(res[0]) + s[0], hi_bf(res[0]) + s[1]), pack_bf2(lo_bf(res[1]) + s[2], hi_bf(res[1]) + s[3])};
-    *reinterpret_cast<u32x2*>(hp) = o;
+    proj_epilogue<WT>(hp, res, s, sc);
     TRACE(3);
 }
 
@@ -301,10 +319,266 @@ __global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __rest
     f32x4 sum = {0, 0, 0, 0};
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) sum += red[sl * 64 + lane];
-    if constexpr (is_fp8<WT>::value) sum *= sc;
-    const u32x2 o = {pack_bf2(lo_bf(res[0]) + sum[0], hi_bf(res[0]) + sum[1]), pack_bf2(lo_bf(res[1]) + sum[2], hi_bf(res[1]) + sum[3])};
-    *reinterpret_cast<u32x2*>(hp) = o;
+    proj_epilogue<WT>(hp, res, sum, sc);
     TRACE(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: WIDE kernels for batches above 16 rows — qkv and the two projections of the 64-row step of the pipelined bench.
+// The per-tile kernels above run one workgroup set per 16-row batch tile.  At 64 rows on the 64-CU decode partition that was 512 / 384
+// workgroups of 1024 threads (ONE resident per CU: > 64 VGPRs) = 6-8 dispatch rounds, every round paying its norm prologue or its X
+// round trips again, and every weight byte crossing a CU four times: dec_qkv 35 us for 6.3 MB, o_proj 16 us for 4.7 MB, down_proj 67 us for
+// 27.5 MB (profiles/r05_decode_attn_stream_ab.txt) — 40 % of the step.  Here ONE workgroup holds ALL batch tiles (TT = 2 or 4) of its
+// output features: a streamed weight fragment feeds TT MFMAs, the grid is one round (<= the CUs the stream may use), and a workgroup
+// takes as many 8-feature units as that needs (NM MFMAs of 16 weight rows = two units each).
+//   * waves = the 16 K slices of the per-tile kernels, same boundaries.  Per output element the arithmetic is theirs exactly: an
+//     MFMA chain over the slice's even k-steps, one over its odd k-steps, their sum, the 16 slice sums added in order, the shared
+//     epilogue (proj_epilogue / qkv_epilogue) — so a row's bits do not depend on the batch it shares (tests:
+//     test_wide_kernels_equal_the_one_tile_kernels_bitwise, test_decode_plans_gpu.py).
+//   * registers, not LDS, bound the bytes in flight (128 per lane at 1024 threads): the two parities run as two PASSES over the slice
+//     with one accumulator set (NM x TT x 4 VGPRs; the even sums wait in the wave's own LDS slots), each pass in rounds of WIDE_G
+//     k-steps = WIDE_G x (NM weight + TT activation fragments) requested together.
+//   * X fragments come straight from the X image in L2 (a wave reads each of its fragments once: nothing to share through LDS).
+//   * dec_qkv_wide has no LDS X image either (64 x 1536 bf16 = 192 KiB would not fit): every wave first computes the RMS statistic of
+//     four rows (row_rstd: the per-tile prologue's own function) -> 64 floats in LDS -> barrier; then it loads the raw residual
+//     fragments of ITS K slice (TT x <= 3 x 16 B per lane, L2 hits) and normalises them in registers (norm8: the same roundings).
+//   * the NM x TT (<= 8) accumulator tiles are reduced and finished by waves 15, 14, ... — one tile each.
+// LDS: [16 slices][NM][TT][64 lanes] f32x4 = NM x TT x 16 KiB (+ 64 floats): one workgroup per CU.
+constexpr int WIDE_G = 3;
+
+template <int NM, int TT, typename WT>
+__global__ __launch_bounds__(1024) void dec_proj_wide_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
+                                                             bf16_t* __restrict__ h, int B, int N, int K, int NU) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                                  // [16][NM][TT][64]
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int m = lane & 15, g = lane >> 4;
+    const int n_tiles = (B + 15) >> 4, n_units = N >> 3;
+    const int u0 = blockIdx.y * NU;                                               // first 8-feature unit of this workgroup (< n_units: launcher)
+    const int KS = K / 32;
+    const int k0 = (int)((uint32_t)(wv * KS) >> 4), k1 = (int)((uint32_t)((wv + 1) * KS) >> 4);
+    // MFMA j multiplies units u0 + 2j (A rows 0-7) and u0 + 2j + 1 (A rows 8-15; a duplicate of the first when the workgroup has no such unit).
+    // Addresses = wave-uniform 64-bit base (scalar registers) + a 32-bit per-lane byte offset: the register file is what bounds this kernel.
+    uint32_t woff[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int ua = min(u0 + 2 * j, n_units - 1);
+        const int ub = (2 * j + 1 < NU && u0 + 2 * j + 1 < n_units) ? u0 + 2 * j + 1 : ua;
+        const int u = (m >> 3) ? ub : ua;
+        woff[j] = (uint32_t)(((size_t)(u >> 1) * KS * 64 + lane_slot<WT>(g, (m & 7) + 8 * (u & 1))) * sizeof(WT));
+    }
+    const char* wbase = reinterpret_cast<const char*>(Wd);
+    const char* zbase = reinterpret_cast<const char*>(g_zero_chunk);
+    const uint32_t zoff = lane * (uint32_t)sizeof(WT);
+    // X image of tile t (XR = 16): fragment (k-step, lane) at byte t * 32 K + k-step * 1024 + lane * 16; tiles past the batch re-read the last one
+    const char* xbase = reinterpret_cast<const char*>(X);
+    const uint32_t xoff = lane * 16u;
+    uint32_t toff[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) toff[t] = (uint32_t)min(t, n_tiles - 1) * 32u * (uint32_t)K;
+    // epilogue role: wave 15 - e finishes accumulator tile e = (MFMA je, batch tile te)
+    const int e = 15 - wv;
+    const bool ew = e < NM * TT;                                                  // wave-uniform
+    const int je = ew ? e / TT : 0, te = ew ? e % TT : 0;
+    const int ul = 2 * je + (g >> 1), unit = u0 + ul, row = 16 * te + m;          // accumulator rows 4g + r: unit ul of the workgroup, features 4 (g & 1) + r
+    const bool epi = ew && ul < NU && unit < n_units && row < B;
+    const int col0 = 8 * min(unit, n_units - 1) + 4 * (g & 1);
+    bf16_t* hp = h + (size_t)min(row, B - 1) * N + col0;
+    TRACE(0);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        f32x4 acc[NM][TT];
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+        for (int kb = k0 + par; kb < k1; kb += 2 * WIDE_G) {                      // wave-uniform trip count
+            WT a[NM][WIDE_G];
+            bf16x8 b[TT][WIDE_G];
+#pragma unroll
+            for (int jj = 0; jj < WIDE_G; ++jj) {
+                const int k = kb + 2 * jj;
+                const bool ok = k < k1;                                           // slots past the slice multiply a chunk of zeros
+                const int kc = min(k, KS - 1);
+                const char* wk = ok ? wbase + (size_t)k * 64 * sizeof(WT) : zbase;                 // wave-uniform
+#pragma unroll
+                for (int j = 0; j < NM; ++j) a[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wk + (ok ? woff[j] : zoff)));
+#pragma unroll
+                for (int t = 0; t < TT; ++t) b[t][jj] = *reinterpret_cast<const bf16x8*>(xbase + (size_t)(toff[t] + (uint32_t)kc * 1024u) + xoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < WIDE_G; ++jj)
+#pragma unroll
+                for (int j = 0; j < NM; ++j) {
+                    const bf16x8 wa = as_a(a[j][jj]);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, b[t][jj], acc[j][t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the wave's own slots: even sums wait here for the odd ones (same lane writes and reads: no barrier)
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4* r = red + ((size_t)((wv * NM + j) * TT + t)) * 64 + lane;
+                if (par == 0) *r = acc[j][t];
+                else *r = *r + acc[j][t];
+            }
+    }
+    TRACE(1);
+    // the residual (and the fp8 scales) only now: through the K loops every register carries fragments; its round trip (an L2 hit) runs
+    // under the barrier and the 16 reduction reads
+    const u32x2 res = *reinterpret_cast<const u32x2*>(hp);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) sc = *reinterpret_cast<const f32x4*>(wscale + col0);
+    __syncthreads();
+    TRACE(2);
+    if (!epi) return;
+    f32x4 sum = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) sum += red[((size_t)((sl * NM + je) * TT + te)) * 64 + lane];
+    proj_epilogue<WT>(hp, res, sum, sc);
+    TRACE(3);
+}
+
+// grid.y = ceil(n_out / NM) workgroups, n_out = (Hq + 2 Hkv) * 8 whole 16-row tiles of the (permuted, launch_pack_frag_qkv) qkv weight.
+template <int NM, int TT, int NC, typename WT>
+__global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
+                                                            const WT* __restrict__ Wd, const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
+                                                            const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
+                                                            const int32_t* __restrict__ block_table, int max_pages,
+                                                            bf16_t* __restrict__ pool, bf16_t* __restrict__ q_out,
+                                                            int B, int H, int Hq, int Hkv, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                                  // [16][NM][TT][64]
+    float* rstd_s = reinterpret_cast<float*>(smem + (size_t)16 * NM * TT * 64 * sizeof(f32x4));     // [16 TT]
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int m = lane & 15, g = lane >> 4;
+    const int n_out = (Hq + 2 * Hkv) * 8, tl0 = blockIdx.y * NM;
+    const int KS = H / 32;
+    const int k0 = wv * KS / 16, k1 = (wv + 1) * KS / 16;                         // k1 - k0 <= NC (launcher)
+    TRACE(0);
+    // ---- 1. one round trip: the rows whose statistic this wave computes (wv, wv + 16, ...), its weight slice, the norm weights of its K
+    // slice, the epilogue waves' small operands
+    u32x4 v[TT][NC];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int r = min(wv + 16 * i, B - 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[i][c] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + min(c * 512 + lane * 8, H - 8));
+    }
+    u32x4 wf[NC];
+#pragma unroll
+    for (int o = 0; o < NC; ++o) wf[o] = *reinterpret_cast<const u32x4*>(ln_w + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
+    const int e = 15 - wv;
+    const bool ew = e < NM * TT;                                                  // wave-uniform
+    const int je = ew ? e / TT : 0, te = ew ? e % TT : 0;
+    const int tile = min(tl0 + je, n_out - 1), head = tile >> 3, j8 = tile & 7;
+    const bool rot = head < Hq + Hkv;
+    const int row = 16 * te + m, mc = min(row, B - 1);
+    const bool epi = ew && tl0 + je < n_out && row < B;
+    const int f0 = rot ? 8 * j8 + 2 * g : 16 * j8 + 4 * g;                        // whole tiles: accumulator rows 4g .. 4g + 3 (dec_qkv_kernel, FULL)
+    const int f1 = rot ? f0 + 64 : f0 + 2;
+    const int pos = ctx_len[mc];
+    const bf16_t* bp = bias ? bias + head * 128 : ln_w;
+    const uint32_t bia0 = *reinterpret_cast<const uint32_t*>(bp + f0), bia1 = *reinterpret_cast<const uint32_t*>(bp + f1);
+    const float fr0 = inv_freq[f0 & 63], fr1 = inv_freq[(f0 + 1) & 63];
+    f32x2 sc0 = {1.f, 1.f}, sc1 = {1.f, 1.f};
+    if constexpr (is_fp8<WT>::value) {
+        sc0 = *reinterpret_cast<const f32x2*>(wscale + head * 128 + f0);
+        sc1 = *reinterpret_cast<const f32x2*>(wscale + head * 128 + f1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const WT* zc = reinterpret_cast<const WT*>(g_zero_chunk) + lane;
+    WT a[NM][NC];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const WT* wp = Wd + (size_t)min(tl0 + j, n_out - 1) * KS * 64 + lane_slot<WT>(g, m);
+#pragma unroll
+        for (int o = 0; o < NC; ++o) a[j][o] = __builtin_nontemporal_load(k0 + o < k1 ? wp + (size_t)(k0 + o) * 64 : zc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int page = block_table[(size_t)mc * max_pages + (pos >> 6)];           // second (dependent) round trip, behind the weights
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. statistics
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) PIN(v[i][c]);
+#pragma unroll
+    for (int o = 0; o < NC; ++o) PIN(wf[o]);
+    TRACE(1);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int r = wv + 16 * i;                                                // wave-uniform
+        if (r < B) {
+            const float rstd = row_rstd<NC>(v[i], H, eps, lane);
+            if (lane == 0) rstd_s[r] = rstd;
+        }
+    }
+    float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
+    if (ew && rot) {                  // precise sincosf, as in dec_qkv_kernel
+        sincosf((float)pos * fr0, &rs[0], &rc[0]);
+        sincosf((float)pos * fr1, &rs[1], &rc[1]);
+    }
+    __syncthreads();
+    TRACE(2);
+    // ---- 3. this wave's K slice of every row, normalised in registers: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7]
+    bf16x8 xf[TT][NC];
+    {
+        u32x4 raw[TT][NC];
+        float rsd[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int r = min(16 * t + m, B - 1);
+            rsd[t] = rstd_s[r];
+#pragma unroll
+            for (int o = 0; o < NC; ++o) raw[t][o] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int o = 0; o < NC; ++o) xf[t][o] = __builtin_bit_cast(bf16x8, norm8(raw[t][o], wf[o], rsd[t]));
+    }
+    TRACE(3);
+    // ---- 4. contraction: even k-steps, then odd k-steps (mfma_lds: acc0 / acc1)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        f32x4 acc[NM][TT];
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int o = par; o < NC; o += 2)
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const bf16x8 wa = as_a(a[j][o]);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xf[t][o], acc[j][t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4* r = red + ((size_t)((wv * NM + j) * TT + t)) * 64 + lane;
+                if (par == 0) *r = acc[j][t];
+                else *r = *r + acc[j][t];
+            }
+    }
+    TRACE(4);
+    PIN(page); PIN(fr0); PIN(fr1); PIN(bia0); PIN(bia1);
+    if constexpr (is_fp8<WT>::value) { PIN(sc0); PIN(sc1); }
+    __syncthreads();
+    TRACE(5);
+    if (!epi) return;
+    f32x4 x = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) x += red[((size_t)((sl * NM + je) * TT + te)) * 64 + lane];
+    qkv_epilogue<WT>(x, rot, head, Hq, Hkv, f0, bias != nullptr, bia0, bia1, sc0, sc1, rc, rs, pos, page, row, pool, q_out);
+    TRACE(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -621,10 +895,52 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
 
 // Wd / wscale of the launchers: wscale == nullptr -> Wd is the bf16 fragment image (launch_pack_frag*), else Wd is the e4m3
 // fragment image (launch_pack_frag_fp8) and wscale its per-row fp32 scales.
+// CUs a decode stream may use: the partition it is masked to, or the device.  DOTS_OCR_DEC_WIDE_CUS overrides (tests, A/B runs; read per call).
+static int wide_cus(int part_cus) {
+    if (const char* e = getenv("DOTS_OCR_DEC_WIDE_CUS")) { const int v = atoi(e); if (v > 0) return v; }
+    if (part_cus > 0) return part_cus;
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
+        n_cus = v;
+    }
+    return n_cus;
+}
+// batches above 16 rows run the wide kernels (DOTS_OCR_DEC_WIDE=0: the per-tile kernels, A/B switch; same bits)
+static bool wide_on() {
+    static const bool on = !(getenv("DOTS_OCR_DEC_WIDE") && atoi(getenv("DOTS_OCR_DEC_WIDE")) == 0);
+    return on;
+}
+
+// part_cus > 0: the stream is CU-masked to that many CUs (the decode partition of the pipelined step): whole 16-row weight tiles per workgroup
+// (half as many workgroups) at B <= 16, as many features per workgroup as one round on those CUs needs above.
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
-                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int full_tiles) {
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
+    const int full_tiles = part_cus > 0;
+    if (B > 16 && wide_on()) {
+        static uint32_t attr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int n_out = (Hq + 2 * Hkv) * 8, cus = wide_cus(part_cus);
+        const int nm = (n_out + cus - 1) / cus >= 2 ? 2 : 1, tt = B <= 32 ? 2 : 4;
+        const size_t lds_w = (size_t)16 * nm * tt * 64 * sizeof(f32x4) + MAX_DECODE_ROWS * sizeof(float);
+        const dim3 grid_w(1, (n_out + nm - 1) / nm);
+        auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+            hipError_t e = ensure_lds(kern, lds_w, done);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid_w, dim3(1024), lds_w, s, h, ln_w, wd, wscale, bias, inv_freq, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps);
+            return hipGetLastError();
+        };
+#define QKV_WIDE(NMV, TTV, IDX)                                                                                                     \
+        return wscale ? go(dec_qkv_wide_kernel<NMV, TTV, NC_MAX, u32x2>, (const u32x2*)Wd, &attr_w[IDX])                              \
+                      : go(dec_qkv_wide_kernel<NMV, TTV, NC_MAX, bf16x8>, (const bf16x8*)Wd, &attr_w[IDX + 1])
+        if (nm == 1 && tt == 2) { QKV_WIDE(1, 2, 0); }
+        if (nm == 1) { QKV_WIDE(1, 4, 2); }
+        if (tt == 2) { QKV_WIDE(2, 2, 4); }
+        QKV_WIDE(2, 4, 6);
+#undef QKV_WIDE
+    }
     static uint32_t attr[4] = {0, 0, 0, 0};
     const int XR = B <= 8 ? 8 : 16;
     const size_t lds = (size_t)XR * H * 2 + 16 * 64 * sizeof(f32x4), lds_max = (size_t)16 * H * 2 + 16 * 64 * sizeof(f32x4);
@@ -639,9 +955,31 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
     return full_tiles ? go(dec_qkv_kernel<NC_MAX, bf16x8, true>, (const bf16x8*)Wd, &attr[2]) : go(dec_qkv_kernel<NC_MAX, bf16x8, false>, (const bf16x8*)Wd, &attr[0]);
 }
 
-// full_tiles: one whole 16-row tile per workgroup (N / 16 workgroups) instead of an 8-row half tile — for a stream CU-masked to half the chip.
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int full_tiles) {
+// part_cus: see launch_dec_qkv
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
+    const int full_tiles = part_cus > 0;
+    if (B > 16 && wide_on()) {
+        static uint32_t attr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int n_units = N / 8, cus = wide_cus(part_cus);
+        const int nu = std::max(1, std::min(4, (n_units + cus - 1) / cus)), nm = (nu + 1) / 2, tt = B <= 32 ? 2 : 4;
+        const size_t lds_w = (size_t)16 * nm * tt * 64 * sizeof(f32x4);
+        const dim3 grid_w(1, (n_units + nu - 1) / nu);
+        auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+            hipError_t e = ensure_lds(kern, lds_w, done);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid_w, dim3(1024), lds_w, s, X, wd, wscale, h, B, N, K, nu);
+            return hipGetLastError();
+        };
+#define PROJ_WIDE(NMV, TTV, IDX)                                                                                                  \
+        return wscale ? go(dec_proj_wide_kernel<NMV, TTV, u32x2>, (const u32x2*)Wd, &attr_w[IDX])                                   \
+                      : go(dec_proj_wide_kernel<NMV, TTV, bf16x8>, (const bf16x8*)Wd, &attr_w[IDX + 1])
+        if (nm == 1 && tt == 2) { PROJ_WIDE(1, 2, 0); }
+        if (nm == 1) { PROJ_WIDE(1, 4, 2); }
+        if (tt == 2) { PROJ_WIDE(2, 2, 4); }
+        PROJ_WIDE(2, 4, 6);
+#undef PROJ_WIDE
+    }
     const int need = (K / 32 + 15) / 16, XR = B <= 8 ? 8 : 16;
     const dim3 grid((B + 15) / 16, full_tiles ? N / 16 : N / 8);
 #define PROJ_LAUNCH(G, F)                                                                                                                        \

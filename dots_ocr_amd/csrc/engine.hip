@@ -1008,12 +1008,12 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
-                          Hkv, c.rms_norm_eps, part));
+                          Hkv, c.rms_norm_eps, part ? e->dec_cus : 0));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale, part ? e->dec_cus : 0, e->attn_stream));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
-        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part));
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part ? e->dec_cus : 0));
         CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0));
-        CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part));
+        CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part ? e->dec_cus : 0));
     }
     CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
     e->B_sel = B;
@@ -1851,7 +1851,7 @@ int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* 
     CK(hipMemcpyAsync(freq, f, sizeof(f), hipMemcpyHostToDevice, e->stream));
     RET(op_weight(e, sc, (const bf16_t*)wqkv, (int64_t)(Hq + 2 * Hkv) * 128, H, Hq, Hkv, true, fp8, &wd, &wscale));
     CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
-                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps));
+                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps, e->force_part ? e->dec_cus : 0));      // dots_set_decode_plan(1): the partition plan's kernels
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
@@ -1888,7 +1888,7 @@ int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout,
     CK(sc.get(&xi, (size_t)(B + 15) / 16 * 16 * K));
     CK(launch_pack_x(e->stream, (const bf16_t*)x, xi, B, K));
     RET(op_weight(e, sc, (const bf16_t*)w, N, K, 0, 0, false, fp8, &wd, &wscale));
-    CK(launch_dec_proj(e->stream, xi, wd, wscale, (bf16_t*)h_inout, B, N, K));
+    CK(launch_dec_proj(e->stream, xi, wd, wscale, (bf16_t*)h_inout, B, N, K, e->force_part ? e->dec_cus : 0));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

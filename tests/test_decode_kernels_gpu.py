@@ -311,6 +311,74 @@ def test_two_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8):
         assert torch.equal(logits[r0:r0 + n].view(torch.int32), l1.view(torch.int32)), f"lm_head rows {r0}..{r0 + n - 1} of {B}"
 
 
+@pytest.mark.parametrize("cus", [None, 100, 64, 48])       # CUs the launcher plans for: whole chip (1 unit / 1 tile per workgroup), 2 units, 3 units / 2 tiles, 4 units
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B", [17, 33, 40, 64])
+def test_wide_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8, cus, monkeypatch):
+    """Round 5: above 16 rows dec_qkv and the two projections run the WIDE kernels (all batch tiles in one workgroup, no LDS X image, parity
+    passes over the K slices; csrc/decode_fused.hip).  Per output element their arithmetic is the per-tile kernels': the rows of a B-row
+    call equal, bit for bit, the same rows computed in calls of at most 16 rows — q, the appended K / V page slots, and both residual
+    projections (o_proj K = 1536, down_proj K = 8960) — for every workgroup shape the launcher can choose (DOTS_OCR_DEC_WIDE_CUS)."""
+    if cus is None:
+        monkeypatch.delenv("DOTS_OCR_DEC_WIDE_CUS", raising=False)
+    else:
+        monkeypatch.setenv("DOTS_OCR_DEC_WIDE_CUS", str(cus))
+    g = torch.Generator().manual_seed(B * 7 + 5)
+    h = bf(torch.randn(B, H, generator=g) * 2)
+    ln_w = bf(1 + 0.1 * torch.randn(H, generator=g))
+    W = bf(torch.randn((HQ + 2 * HKV) * 128, H, generator=g) * 0.02)
+    bias = bf(torch.randn((HQ + 2 * HKV) * 128, generator=g) * 0.1)
+    positions = [(977 * i + 63) % 7000 for i in range(B)]
+    pos = torch.tensor(positions, dtype=torch.int32)
+    max_pages = 128
+    perm = torch.randperm(B + 3, generator=g)[:B]
+    table = torch.zeros((B, max_pages), dtype=torch.int32)
+    for b in range(B):
+        table[b, positions[b] >> 6] = int(perm[b])
+    sentinel = 0x7F7F
+    hd, lnd, Wd_, bd, ctx_d, tab_d = dev(h), dev(ln_w), dev(W), dev(bias), dev(pos), dev(table)
+
+    def qkv(r0, n):
+        pool = dev(torch.full((B + 3, HKV, 2, 8192), sentinel, dtype=torch.int16))
+        q = torch.zeros(n, HQ * 128, dtype=torch.bfloat16, device="cuda")
+        hs, cs, ts = hd[r0:r0 + n].contiguous(), ctx_d[r0:r0 + n].contiguous(), tab_d[r0:r0 + n].contiguous()
+        torch.cuda.synchronize()
+        eng.op_dec_qkv(hs.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), bd.data_ptr(), cs.data_ptr(), ts.data_ptr(), max_pages, pool.data_ptr(),
+                       q.data_ptr(), n, H, HQ, HKV, EPS, THETA, fp8=fp8)
+        eng.synchronize()
+        return q, pool
+
+    q_all, pool_all = qkv(0, B)
+    assert float(q_all.float().abs().max()) > 0
+    pool_tiles = torch.full_like(pool_all, sentinel)
+    for r0 in range(0, B, 16):
+        n = min(16, B - r0)
+        q1, p1 = qkv(r0, n)
+        assert torch.equal(q_all[r0:r0 + n].view(torch.int16), q1.view(torch.int16)), f"q rows {r0}..{r0 + n - 1} of {B}"
+        wrote = p1 != sentinel
+        assert not (wrote & (pool_tiles != sentinel)).any()
+        pool_tiles[wrote] = p1[wrote]
+    assert torch.equal(pool_all, pool_tiles), f"K / V page slots of a {B}-row call differ from the per-tile calls"
+
+    for N, K in [(H, HQ * 128), (H, I)]:
+        x = bf(torch.randn(B, K, generator=g))
+        Wp = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+        r = bf(torch.randn(B, N, generator=g) * 2)
+        xd, Wpd = dev(x), dev(Wp)
+        h_all = dev(r.clone())
+        torch.cuda.synchronize()
+        eng.op_dec_proj(xd.data_ptr(), Wpd.data_ptr(), h_all.data_ptr(), B, N, K, fp8=fp8)
+        eng.synchronize()
+        assert not torch.equal(h_all.cpu(), r)
+        for r0 in range(0, B, 16):
+            n = min(16, B - r0)
+            h1, xs = dev(r[r0:r0 + n].clone()), xd[r0:r0 + n].contiguous()
+            torch.cuda.synchronize()
+            eng.op_dec_proj(xs.data_ptr(), Wpd.data_ptr(), h1.data_ptr(), n, N, K, fp8=fp8)
+            eng.synchronize()
+            assert torch.equal(h_all[r0:r0 + n].view(torch.int16), h1.view(torch.int16)), f"proj K={K} rows {r0}..{r0 + n - 1} of {B}"
+
+
 def test_decode_kernels_reject_unsupported_shapes(eng):
     from dots_ocr_amd.engine import DotsEngineError
     z = torch.zeros(65 * 2048, dtype=torch.bfloat16, device="cuda")
