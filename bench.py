@@ -660,6 +660,10 @@ def main():
                             "after); per step exactly one preprocessing pass, one tower, one prefill, one decode loop; phase_ms_per_step therefore "
                             "OVERLAP and sum to more than ms_per_step" % (dec_cus, dec_cus - 1),
                     "dec_cus": 256 if sliced else dec_cus, "vit_cus": 256 if sliced else 256 - dec_cus,
+                    "tower_tail_blocks": None if sliced else eng.tower_tail(),
+                    "tower_tail_note": "the last tower_tail_blocks of the 42 tower blocks (and the merger) run on the whole chip, not on the tower partition: the "
+                                       "engine sizes the partition part from the previous step's events so that it ends with the decode loop (dots_tower_tail; "
+                                       "partitions cannot be re-balanced finer than 32 CUs: with 56 decode CUs every decode kernel runs at half speed)",
                     "time_sliced": ("no CU partitions: the tower of the new batch, its prefill and the decode steps over all rows in flight take turns on the "
                                     "whole chip (the 'mode' text above describes the partitioned default)") if sliced else None,
                     "batches_decoding_together": rif // B if deep else 1,

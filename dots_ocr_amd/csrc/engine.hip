@@ -133,6 +133,20 @@ struct DotsEngine {
     int64_t pref_patches = 0;
     std::vector<int64_t> pref_grid;
     hipStream_t vs = nullptr;              // the stream vit_forward is currently enqueuing to (stream or s_vit)
+    // ---- tower tail (round 5): the LAST `tail` blocks of a prefetched tower (and its merger) run on `s_vit_full`, a stream without a CU
+    // mask.  The two partitions cannot be re-balanced in small steps (a partition has to be a whole number of CUs per shader engine of
+    // every XCD — 32, 64, 96, ... CUs: with 56 every decode kernel ran at half speed, profiles/r05_decode_wide_ab.txt), so when the
+    // decode loop of a step drains before the tower the decode partition would idle until the tower is done.  Instead the tower is split
+    // in time: (L - tail) blocks beside the decode loop on its partition, the rest on the whole chip.  tail is chosen per launch from the
+    // previous launch's measurements (events): tail = L - D / t_block, D = when the last decode chunk ended after the tower had started,
+    // t_block = the partition's time per block — i.e. the head ends about when the decode loop does; a decode loop that outlasts the
+    // tower gives tail = 0.  DOTS_OCR_TOWER_TAIL_LAYERS=n fixes it (0 = off).
+    hipStream_t s_vit_full = nullptr;
+    hipEvent_t ev_tw0 = nullptr, ev_tw_sw = nullptr, ev_dec_end = nullptr;      // tower start / end of its partition part / end of the last decode chunk
+    int tail_fixed = -1;                   // DOTS_OCR_TOWER_TAIL_LAYERS, or -1 = adaptive
+    int tail_now = 0;                      // tail of the tower being launched / launched last
+    int tail_head_blocks = 0;              // blocks of the last prefetched tower that ran on the partition (0: no measurement yet)
+    uint64_t tw_seq = 0, dec_end_seq = 0, dec_end_at_tw = 0;     // launch counters: was a decode chunk recorded after the last tower started?
     std::vector<LLayer> ll;
     float *v_inv_freq = nullptr, *lm_inv_freq = nullptr;
 
@@ -560,6 +574,7 @@ int alloc_workspaces(DotsEngine* e) {
         e->force_part = plan & 1;
         e->attn_stream = (plan & 2) ? 1 : (plan & 4) ? 0 : -1;
     }
+    if (const char* v = getenv("DOTS_OCR_TOWER_TAIL_LAYERS")) e->tail_fixed = std::max(-1, std::min(atoi(v), c.v_layers));      // dots_tower_tail
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
     // keeps appending K/V at position 0 of whatever page its row names; it must never be a page a live sequence owns)
     e->hp_table.assign((size_t)mb * e->max_pages, e->n_pool_pages);
@@ -664,6 +679,8 @@ int check_vision_request(DotsEngine* e, int64_t N, const int64_t* grid, int n_im
     return DOTS_OK;
 }
 
+int chain_streams(DotsEngine* e, hipStream_t from, hipStream_t to);
+
 int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* grid, int n_img, void* out_dev, bf16_t* vis_out, int64_t* rows_out) {
     const DotsConfig& c = e->cfg;
     hipStream_t s = e->vs;
@@ -706,8 +723,19 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     CK(launch_rope_table(s, e->v_pos, e->v_inv_freq, e->v_cs, N, 1));
     const float scale = 1.0f / sqrtf(128.0f);
     e->attn_pairs = 0;
+    // a prefetched tower: its last e->tail_now blocks and the merger run on the unmasked stream (DotsEngine::s_vit_full)
+    hipStream_t const s_first = s;
+    const bool prefetched = e->s_vit && s == e->s_vit && e->s_vit_full;
+    const int switch_at = prefetched ? c.v_layers - std::max(0, std::min(e->tail_now, c.v_layers - 1)) : -1;
+    if (prefetched) CK(hipEventRecord(e->ev_tw0, s));
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = e->vl[i];
+        if (i == switch_at) {
+            CK(hipEventRecord(e->ev_tw_sw, s));
+            e->tail_head_blocks = i;
+            RET(chain_streams(e, s, e->s_vit_full));
+            e->vs = s = e->s_vit_full;
+        }
         CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
         RET(vdense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
         CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
@@ -724,6 +752,10 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
             e->dbg_vit_rows = N;
         }
     }
+    if (prefetched && switch_at == c.v_layers) {         // tail 0: the whole tower ran on the partition
+        CK(hipEventRecord(e->ev_tw_sw, s));
+        e->tail_head_blocks = c.v_layers;
+    }
     const bf16_t* xin = e->v_x;
     if (c.v_post_norm) {
         CK(launch_rmsnorm(s, e->v_x, e->v_post_norm, e->v_xn, N, E, c.v_rms_eps));
@@ -734,6 +766,10 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     const int64_t R = N / g;
     RET(vdense(e, e->v_att, e->m0_w, e->m0_8, e->m0_s, e->m0_b, nullptr, e->v_mh, R, Mg, Mg, Mg, EPI_GELU));
     RET(vdense(e, e->v_mh, e->m2_w, e->m2_8, e->m2_s, e->m2_b, nullptr, vis_out, R, c.hidden_size, Mg, c.hidden_size, EPI_NONE));
+    if (s != s_first) {                                  // back to the stream the caller orders things on
+        RET(chain_streams(e, s, s_first));
+        e->vs = s = s_first;
+    }
     CK(hipEventRecord(e->ev[1], s));
     *rows_out = R;
     if (out_dev) CK(hipMemcpyAsync(out_dev, vis_out, (size_t)R * c.hidden_size * 2, hipMemcpyDeviceToDevice, s));
@@ -790,7 +826,27 @@ int ensure_overlap_streams(DotsEngine* e) {
     }
     CK(hipEventCreateWithFlags(&e->ev_vis_ready, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&e->ev_xs, hipEventDisableTiming));
+    CK(hipStreamCreateWithFlags(&e->s_vit_full, hipStreamNonBlocking));
+    CK(hipEventCreate(&e->ev_tw0));
+    CK(hipEventCreate(&e->ev_tw_sw));
+    CK(hipEventCreate(&e->ev_dec_end));
     return DOTS_OK;
+}
+
+// blocks of the next prefetched tower that run on the whole chip (see DotsEngine::s_vit_full)
+int pick_tower_tail(DotsEngine* e) {
+    const int L = e->cfg.v_layers;
+    if (e->tail_fixed >= 0) return std::min(e->tail_fixed, L - 1);
+    if (e->tail_head_blocks <= 0 || e->dec_end_seq <= e->dec_end_at_tw) return e->tail_now;      // nothing measured since the last tower started
+    float head_ms = 0.f, d_ms = 0.f;
+    if (hipEventElapsedTime(&head_ms, e->ev_tw0, e->ev_tw_sw) != hipSuccess || hipEventElapsedTime(&d_ms, e->ev_tw0, e->ev_dec_end) != hipSuccess) {
+        (void)hipGetLastError();                         // not finished / not comparable: keep the current split
+        return e->tail_now;
+    }
+    if (head_ms <= 0.f) return e->tail_now;
+    const float t_block = head_ms / (float)e->tail_head_blocks;
+    const int tail = d_ms <= 0.f ? L / 2 : (int)floorf((float)L - d_ms / t_block);
+    return std::max(0, std::min(tail, L / 2));
 }
 
 // make `to` wait for everything enqueued on `from` so far
@@ -830,6 +886,9 @@ int stage_pixels(DotsEngine* e, hipStream_t st, const float* pixel_values, int o
 // the tower of the prefetch request, on the side stream, behind everything the main stream holds so far
 int launch_prefetched_tower(DotsEngine* e) {
     e->pref_deferred = false;
+    e->tail_now = pick_tower_tail(e);
+    e->dec_end_at_tw = e->dec_end_seq;
+    ++e->tw_seq;
     RET(chain_streams(e, e->stream, e->s_vit));          // the pixels (dots_preprocess_image), an earlier tower pass, the prefill it was deferred behind
     e->vs = e->s_vit;
     int r = vit_forward(e, e->pref_pix, e->pref_patches, e->pref_grid.data(), (int)(e->pref_grid.size() / 3), nullptr, e->vis_pref, &e->vis_pref_rows);
@@ -1149,9 +1208,12 @@ void dots_destroy(DotsEngine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->s_vit) hipStreamSynchronize(e->s_vit);
+    if (e->s_vit_full) hipStreamSynchronize(e->s_vit_full);
     if (e->s_dec) hipStreamSynchronize(e->s_dec);
     if (e->stream) hipStreamSynchronize(e->stream);
     drop_step_graphs(e);
+    for (hipEvent_t ev : {e->ev_tw0, e->ev_tw_sw, e->ev_dec_end}) if (ev) hipEventDestroy(ev);
+    if (e->s_vit_full) hipStreamDestroy(e->s_vit_full);
     if (e->ev_vis_ready) hipEventDestroy(e->ev_vis_ready);
     if (e->ev_xs) hipEventDestroy(e->ev_xs);
     if (e->s_vit) hipStreamDestroy(e->s_vit);
@@ -1450,6 +1512,7 @@ int dots_slots_decode(DotsEngine* e, int n_steps) {
         if (exec) { if (hipGraphLaunch(exec, cur) != hipSuccess) r = e->fail(DOTS_E_HIP, "hipGraphLaunch failed"); }
         else r = decode_step_launches(e, n_splits);
     }
+    if (r == DOTS_OK && e->ev_dec_end && hipEventRecord(e->ev_dec_end, cur) == hipSuccess) ++e->dec_end_seq;      // pick_tower_tail
     if (r == DOTS_OK) r = chain_streams(e, cur, s);
     e->B = 0;
     e->stats.decode_steps += n_steps;
@@ -1611,6 +1674,14 @@ int dots_set_decode_plan(DotsEngine* e, int plan) {
         e->attn_stream = stream;
         drop_step_graphs(e);                               // the captured decode steps bake the launch plan in
     }
+    return DOTS_OK;
+}
+
+int dots_tower_tail(DotsEngine* e, int set, int* now) {
+    if (!e) return DOTS_E_INVALID;
+    if (set < -2 || set > e->cfg.v_layers) return e->fail(DOTS_E_INVALID, "tower tail must be -2 (query), -1 (adaptive) or 0 .. v_layers");
+    if (set >= -1) e->tail_fixed = set;
+    if (now) *now = e->tail_now;
     return DOTS_OK;
 }
 

@@ -74,6 +74,7 @@ def _prototypes(lib):
         "dots_set_sampling": (i32, [vp, f32, f32, C.c_uint64]),
         "dots_set_decode_plan": (i32, [vp, i32]),
         "dots_set_gemm_plan": (i32, [vp, i32]),
+        "dots_tower_tail": (i32, [vp, i32, P(i32)]),
         "dots_slot_capacity": (i32, [vp, i32, P(i32), P(i32)]),
         "dots_slots_reset": (i32, [vp]),
         "dots_set_eos": (i32, [vp, P(i32), i32]),
@@ -119,7 +120,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_set_gemm_plan", "dots_get_logits",
+    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_set_gemm_plan", "dots_tower_tail", "dots_get_logits",
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info", "dots_slot_capacity", "dots_slots_reset",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
@@ -321,6 +322,14 @@ class Engine:
     def set_gemm_plan(self, plan: int):
         """0 = 8-wave ping-pong GEMM, 1 = one wave per SIMD (round 5); process-wide, bit-identical results."""
         self._ck(self.lib.dots_set_gemm_plan(self.h, int(plan)), "dots_set_gemm_plan")
+
+    def tower_tail(self, set: int = -2) -> int:
+        """Blocks of a prefetched tower that run on the whole chip instead of the tower's CU partition: set = -1 adaptive (default: sized
+        from the previous launch's events so that the partition part ends with the decode loop), >= 0 fixed (0 = off), -2 = query only.
+        Returns the tail of the tower launched last."""
+        now = C.c_int32(0)
+        self._ck(self.lib.dots_tower_tail(self.h, int(set), C.byref(now)), "dots_tower_tail")
+        return int(now.value)
 
     def decode_step(self):
         self._ck(self.lib.dots_decode_step(self.h), "dots_decode_step")

@@ -163,10 +163,19 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
  * while the step is replayed on the decode CU partition beside a prefetched vision tower (dots_vit_prefetch) — the PARTITION plan: the
  * projections as whole 16-row tiles (half as many workgroups) and gate|up as one resident round of workgroups that walk the tile pairs.
  * 1 = the partition plan on every step (tests, A/B runs; slower on the whole chip).  Environment DOTS_OCR_DECODE_PLAN sets the default.
+ * Batches above 16 rows run the WIDE qkv / projection kernels under either plan (round 5: every batch tile in one workgroup, one dispatch
+ * round sized for the CUs of the stream; DOTS_OCR_DEC_WIDE=0 = the per-tile kernels, same bits).
  * Round 5: + 2 = the STREAMING decode-attention kernel (one resident workgroup per CU walks the (row, kv head, split) items, pages arrive by
- * LDS-DMA one item ahead) wherever it is legal, + 4 = always one workgroup per item; neither bit = streaming when every CU of the stream
- * gets at least 6 items (the 64-row step of the pipelined bench).  Same bits either way. */
+ * LDS-DMA one item ahead) wherever it is legal, + 4 = always one workgroup per item (also the default: the streaming kernel measured
+ * slower at every batch size, profiles/r05_decode_attn_stream_ab.txt).  Same bits either way. */
 int dots_set_decode_plan(DotsEngine* e, int plan);
+/* Tower tail of the vision prefetch (round 5).  A prefetched tower (dots_vit_prefetch) runs on the upper CU partition beside the decode
+ * loop; its LAST `tail` blocks (and the merger) run on the whole chip instead, so that the decode partition does not idle when the decode
+ * loop of a step drains before the tower.  set = -1: adaptive (default) — per launch, from the events of the previous one: the partition
+ * part is sized to end when the last decode chunk did (a decode loop that outlasts the tower gives 0); set >= 0: that many blocks on every
+ * launch (0 = off); set = -2: leave it as it is.  Environment DOTS_OCR_TOWER_TAIL_LAYERS = the initial `set`.  *now (may be NULL) receives the tail of the tower
+ * launched last.  Results do not depend on it (the same kernels in the same order). */
+int dots_tower_tail(DotsEngine* e, int set, int* now);
 /* Launch plan of the 256-wide bf16 MFMA GEMM behind the vision tower and the prefill (results are bit-identical under either plan:
  * the same MFMAs in the same k order per output element).  0 = 8 waves per workgroup, two per SIMD running half a K sub-tile apart
  * (round 2); 1 (default) = 4 waves, one per SIMD owning a 128 x 128 output block in 256 accumulator registers, K tiles of 64 streamed by

@@ -115,8 +115,11 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
         eng.vit_take()
         # as bench.py: the NEXT batch's tower is deferred behind this batch's prefill and runs beside its decode loop (the last batch
         # prefetches batch 0 again so that its decode loop, too, runs on the partition)
+        if k == 1:
+            eng.tower_tail(5)                        # round 5: the last 5 blocks of this prefetched tower (and the merger) on the unmasked stream
         eng.vit_prefetch(dev[(k + 1) % 2].data_ptr(), batches[(k + 1) % 2][1], on_device=True, after_prefill=True)
         got.append(eng.generate(ids, lens, max_new_tokens=NEW, vision_taken=True))
+    assert eng.tower_tail(-1) == 5                   # the tail the last tower was launched with; back to adaptive
     eng.vit_take()
     third = eng.generate(batches[0][2], batches[0][3], max_new_tokens=NEW, vision_taken=True)      # the rows prefetched beside batch 1's decode loop
     for k, ((a, an), (b, bn)) in enumerate(zip(seq, got)):
