@@ -437,6 +437,8 @@ def main():
         if deep:
             eng.set_eos([])
             eng.slots_reset()                        # sequence-slot mode: every slot free, every KV page in the pool (drops any pending prefetch)
+        if deep and not sliced and "DOTS_OCR_TOWER_TAIL_LAYERS" not in os.environ:
+            eng.tower_tail(-1)                       # a step's decode work is finite here (half_steps): the tower's last blocks take the whole chip once it has drained
         if not sliced:
             eng.vit_prefetch(pix_dev, np.asarray(preprocess_all(), np.int64), on_device=True)
         if deep:

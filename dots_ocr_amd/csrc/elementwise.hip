@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int32_t* __restri
     cs[i] = make_float2(c, sn);
 }
 
-// grid (tiles, Hq + 2*Hkv).  Slot < Hq+Hkv: rope a 64-token x 128-d head tile into head-major q/k.
-// Slot >= Hq+Hkv: transpose a V tile into V^T [Hkv][128][Tpad] with the 16-key group order
+// grid (tiles, ceil((Hq + Hkv) / ROPE_HPB) + Hkv).  Slot < the number of head groups: rope the 64-token x 128-d tiles of ROPE_HPB q / k heads
+// into head-major q / k — the (cos, sin) row of a token is fetched ONCE per workgroup and re-used for its heads (round 5: one workgroup per
+// head read the 32-KB table tile again for every head, as many bytes as the head tile it moved; same arithmetic per element).
+// Other slots: transpose a V tile into V^T [Hkv][128][Tpad] with the 16-key group order
 // 0-3,8-11,4-7,12-15 (the k-index order of the PV MFMA's B operand, see attn_prefill.hip) and zero
 // padding for tokens past the sequence end.
+constexpr int ROPE_HPB = 4;
 __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const bf16_t* __restrict__ qkv, const float2* __restrict__ cs,
                                                              const Tile64* __restrict__ tiles, bf16_t* __restrict__ q,
                                                              bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
@@ -135,33 +138,40 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const bf16_t* __res
     const int slot = blockIdx.y;
     const int ld = (Hq + 2 * Hkv) * 128;
     const int tid = threadIdx.x;
-    if (slot < Hq + Hkv) {
-        bf16_t* dst = slot < Hq ? q + (size_t)slot * T * 128 : k + (size_t)(slot - Hq) * T * 128;
+    const int n_groups = (Hq + Hkv + ROPE_HPB - 1) / ROPE_HPB;
+    if (slot < n_groups) {
+        const int h_end = min((slot + 1) * ROPE_HPB, Hq + Hkv);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int item = it * 256 + tid;
             const int tok = item >> 3, c = item & 7;           // 8 lanes per token, 8 d's each (+ partner d+64)
             if (tok >= tl.n) continue;
             const int64_t t = tl.tok0 + tok;
-            const bf16_t* src = qkv + t * ld + slot * 128 + c * 8;
-            u32x4 xl = *reinterpret_cast<const u32x4*>(src);
-            u32x4 xh = *reinterpret_cast<const u32x4*>(src + 64);
             const float2* tab = cs + t * 64 + c * 8;
-            u32x4 ol, oh;
+            float2 cc[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float2 c0 = tab[2 * e], c1 = tab[2 * e + 1];
-                float a0 = lo_bf(xl[e]), a1 = hi_bf(xl[e]), b0 = lo_bf(xh[e]), b1 = hi_bf(xh[e]);
-                // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
-                ol[e] = pack_bf2(a0 * c0.x - b0 * c0.y, a1 * c1.x - b1 * c1.y);
-                oh[e] = pack_bf2(b0 * c0.x + a0 * c0.y, b1 * c1.x + a1 * c1.y);
+            for (int e = 0; e < 8; ++e) cc[e] = tab[e];
+            for (int hh = slot * ROPE_HPB; hh < h_end; ++hh) {
+                bf16_t* dst = hh < Hq ? q + (size_t)hh * T * 128 : k + (size_t)(hh - Hq) * T * 128;
+                const bf16_t* src = qkv + t * ld + hh * 128 + c * 8;
+                u32x4 xl = *reinterpret_cast<const u32x4*>(src);
+                u32x4 xh = *reinterpret_cast<const u32x4*>(src + 64);
+                u32x4 ol, oh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float2 c0 = cc[2 * e], c1 = cc[2 * e + 1];
+                    float a0 = lo_bf(xl[e]), a1 = hi_bf(xl[e]), b0 = lo_bf(xh[e]), b1 = hi_bf(xh[e]);
+                    // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
+                    ol[e] = pack_bf2(a0 * c0.x - b0 * c0.y, a1 * c1.x - b1 * c1.y);
+                    oh[e] = pack_bf2(b0 * c0.x + a0 * c0.y, b1 * c1.x + a1 * c1.y);
+                }
+                bf16_t* d = dst + t * 128 + c * 8;
+                *reinterpret_cast<u32x4*>(d) = ol;
+                *reinterpret_cast<u32x4*>(d + 64) = oh;
             }
-            bf16_t* d = dst + t * 128 + c * 8;
-            *reinterpret_cast<u32x4*>(d) = ol;
-            *reinterpret_cast<u32x4*>(d + 64) = oh;
         }
     } else {
-        const int h = slot - Hq - Hkv;
+        const int h = slot - n_groups;
         // load 64 tokens x 128 d (16 B per lane), zero rows past n
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -253,7 +263,7 @@ hipError_t launch_rope_table(hipStream_t s, const int32_t* pos, const float* inv
 hipError_t launch_qkv_rope_split(hipStream_t s, const bf16_t* qkv, const float2* cs, const Tile64* tiles, int n_tiles,
                                  bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv) {
     if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(n_tiles, Hq + 2 * Hkv), dim3(256), 0, s, qkv, cs, tiles, q, k, vt, T, Tpad, Hq, Hkv);
+    hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(n_tiles, (Hq + Hkv + ROPE_HPB - 1) / ROPE_HPB + Hkv), dim3(256), 0, s, qkv, cs, tiles, q, k, vt, T, Tpad, Hq, Hkv);
     return hipGetLastError();
 }
 

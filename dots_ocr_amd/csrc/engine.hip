@@ -140,10 +140,13 @@ struct DotsEngine {
     // in time: (L - tail) blocks beside the decode loop on its partition, the rest on the whole chip.  tail is chosen per launch from the
     // previous launch's measurements (events): tail = L - D / t_block, D = when the last decode chunk ended after the tower had started,
     // t_block = the partition's time per block — i.e. the head ends about when the decode loop does; a decode loop that outlasts the
-    // tower gives tail = 0.  DOTS_OCR_TOWER_TAIL_LAYERS=n fixes it (0 = off).
+    // tower gives tail = 0.  OFF by default (tail 0): the rule assumes that the decode work of a step is FINITE (bench.py's fixed
+    // half_steps per admission); a serving loop whose host merely stopped issuing chunks while it waited for the tower would be read as
+    // "decode drained".  Measured on the a4 bench: 5.74 (off) -> 5.81 pages/s (adaptive, 8 blocks) — the chip is power-limited, a block
+    // on 256 CUs takes 27.6 ms against 30.4 on 192 (profiles/r05_tower_tail_ab.txt).
     hipStream_t s_vit_full = nullptr;
     hipEvent_t ev_tw0 = nullptr, ev_tw_sw = nullptr, ev_dec_end = nullptr;      // tower start / end of its partition part / end of the last decode chunk
-    int tail_fixed = -1;                   // DOTS_OCR_TOWER_TAIL_LAYERS, or -1 = adaptive
+    int tail_fixed = 0;                    // dots_tower_tail / DOTS_OCR_TOWER_TAIL_LAYERS: blocks on the whole chip (default 0 = off), -1 = adaptive
     int tail_now = 0;                      // tail of the tower being launched / launched last
     int tail_head_blocks = 0;              // blocks of the last prefetched tower that ran on the partition (0: no measurement yet)
     uint64_t tw_seq = 0, dec_end_seq = 0, dec_end_at_tw = 0;     // launch counters: was a decode chunk recorded after the last tower started?

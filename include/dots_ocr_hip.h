@@ -171,9 +171,9 @@ int dots_set_sampling(DotsEngine* e, float temperature, float top_p, uint64_t se
 int dots_set_decode_plan(DotsEngine* e, int plan);
 /* Tower tail of the vision prefetch (round 5).  A prefetched tower (dots_vit_prefetch) runs on the upper CU partition beside the decode
  * loop; its LAST `tail` blocks (and the merger) run on the whole chip instead, so that the decode partition does not idle when the decode
- * loop of a step drains before the tower.  set = -1: adaptive (default) — per launch, from the events of the previous one: the partition
- * part is sized to end when the last decode chunk did (a decode loop that outlasts the tower gives 0); set >= 0: that many blocks on every
- * launch (0 = off); set = -2: leave it as it is.  Environment DOTS_OCR_TOWER_TAIL_LAYERS = the initial `set`.  *now (may be NULL) receives the tail of the tower
+ * loop of a step drains before the tower.  set = -1: adaptive — per launch, from the events of the previous one: the partition
+ * part is sized to end when the last decode chunk did (a decode loop that outlasts the tower gives 0; for pipelines whose decode work per
+ * admission is finite, as bench.py's); set >= 0: that many blocks on every launch (0 = off, the default); set = -2: leave it as it is.  Environment DOTS_OCR_TOWER_TAIL_LAYERS = the initial `set`.  *now (may be NULL) receives the tail of the tower
  * launched last.  Results do not depend on it (the same kernels in the same order). */
 int dots_tower_tail(DotsEngine* e, int set, int* now);
 /* Launch plan of the 256-wide bf16 MFMA GEMM behind the vision tower and the prefill (results are bit-identical under either plan:
