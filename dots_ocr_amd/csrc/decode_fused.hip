@@ -346,7 +346,9 @@ __global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __rest
 // LDS: [16 slices][NM][TT][64 lanes] f32x4 = NM x TT x 16 KiB (+ 64 floats): one workgroup per CU.
 constexpr int WIDE_G = 3;
 
-template <int NM, int TT, typename WT>
+// ONE: the whole slice is at most WIDE_G k-steps (o_proj: K = 1536 -> 3): both parities' fragments are requested in ONE round (the
+// in-kernel timeline showed two dependent round trips of ~3 us each on the partition, profiles/r05_decode_trace_b64_partition.txt).
+template <int NM, int TT, typename WT, bool ONE>
 __global__ __launch_bounds__(1024) void dec_proj_wide_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, const float* __restrict__ wscale,
                                                              bf16_t* __restrict__ h, int B, int N, int K, int NU) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,6 +387,46 @@ __global__ __launch_bounds__(1024) void dec_proj_wide_kernel(const bf16_t* __res
     const int col0 = 8 * min(unit, n_units - 1) + 4 * (g & 1);
     bf16_t* hp = h + (size_t)min(row, B - 1) * N + col0;
     TRACE(0);
+    if constexpr (ONE) {
+        WT a[NM][WIDE_G];
+        bf16x8 b[TT][WIDE_G];
+#pragma unroll
+        for (int o = 0; o < WIDE_G; ++o) {
+            const int k = k0 + o;
+            const bool ok = k < k1;
+            const int kc = min(k, KS - 1);
+            const char* wk = ok ? wbase + (size_t)k * 64 * sizeof(WT) : zbase;
+#pragma unroll
+            for (int j = 0; j < NM; ++j) a[j][o] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wk + (ok ? woff[j] : zoff)));
+#pragma unroll
+            for (int t = 0; t < TT; ++t) b[t][o] = *reinterpret_cast<const bf16x8*>(xbase + (size_t)(toff[t] + (uint32_t)kc * 1024u) + xoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            f32x4 acc[NM][TT];
+#pragma unroll
+            for (int j = 0; j < NM; ++j)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int o = par; o < WIDE_G; o += 2)
+#pragma unroll
+                for (int j = 0; j < NM; ++j) {
+                    const bf16x8 wa = as_a(a[j][o]);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, b[t][o], acc[j][t], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < NM; ++j)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    f32x4* r = red + ((size_t)((wv * NM + j) * TT + t)) * 64 + lane;
+                    if (par == 0) *r = acc[j][t];
+                    else *r = *r + acc[j][t];
+                }
+        }
+    } else
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         f32x4 acc[NM][TT];
@@ -518,6 +560,19 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
             if (lane == 0) rstd_s[r] = rstd;
         }
     }
+    // ---- 3. this wave's K slice of every row: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7].  The raw fragments are
+    // requested BEFORE the barrier (their addresses do not need the statistics; the registers of the statistic rows are free now), and
+    // the epilogue waves' sincosf runs while they fly: the second round trip, the barrier wait and the trigonometry overlap.
+    bf16x8 xf[TT][NC];
+    u32x4 raw[TT][NC];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int r = min(16 * t + m, B - 1);
+#pragma unroll
+        for (int o = 0; o < NC; ++o) raw[t][o] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
     if (ew && rot) {                  // precise sincosf, as in dec_qkv_kernel
         sincosf((float)pos * fr0, &rs[0], &rc[0]);
@@ -525,18 +580,10 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
     }
     __syncthreads();
     TRACE(2);
-    // ---- 3. this wave's K slice of every row, normalised in registers: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7]
-    bf16x8 xf[TT][NC];
     {
-        u32x4 raw[TT][NC];
         float rsd[TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const int r = min(16 * t + m, B - 1);
-            rsd[t] = rstd_s[r];
-#pragma unroll
-            for (int o = 0; o < NC; ++o) raw[t][o] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
-        }
+        for (int t = 0; t < TT; ++t) rsd[t] = rstd_s[min(16 * t + m, B - 1)];
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
@@ -960,8 +1007,9 @@ hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int full_tiles = part_cus > 0;
     if (B > 16 && wide_on()) {
-        static uint32_t attr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        static uint32_t attr_w[16] = {0};
         const int n_units = N / 8, cus = wide_cus(part_cus);
+        const bool one = (K / 32 + 15) / 16 <= WIDE_G;                            // a slice is at most WIDE_G k-steps: one round
         const int nu = std::max(1, std::min(4, (n_units + cus - 1) / cus)), nm = (nu + 1) / 2, tt = B <= 32 ? 2 : 4;
         const size_t lds_w = (size_t)16 * nm * tt * 64 * sizeof(f32x4);
         const dim3 grid_w(1, (n_units + nu - 1) / nu);
@@ -972,8 +1020,10 @@ hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const
             return hipGetLastError();
         };
 #define PROJ_WIDE(NMV, TTV, IDX)                                                                                                  \
-        return wscale ? go(dec_proj_wide_kernel<NMV, TTV, u32x2>, (const u32x2*)Wd, &attr_w[IDX])                                   \
-                      : go(dec_proj_wide_kernel<NMV, TTV, bf16x8>, (const bf16x8*)Wd, &attr_w[IDX + 1])
+        if (one) return wscale ? go(dec_proj_wide_kernel<NMV, TTV, u32x2, true>, (const u32x2*)Wd, &attr_w[8 + IDX])               \
+                               : go(dec_proj_wide_kernel<NMV, TTV, bf16x8, true>, (const bf16x8*)Wd, &attr_w[8 + IDX + 1]);         \
+        return wscale ? go(dec_proj_wide_kernel<NMV, TTV, u32x2, false>, (const u32x2*)Wd, &attr_w[IDX])                            \
+                      : go(dec_proj_wide_kernel<NMV, TTV, bf16x8, false>, (const bf16x8*)Wd, &attr_w[IDX + 1])
         if (nm == 1 && tt == 2) { PROJ_WIDE(1, 2, 0); }
         if (nm == 1) { PROJ_WIDE(1, 4, 2); }
         if (tt == 2) { PROJ_WIDE(2, 2, 4); }

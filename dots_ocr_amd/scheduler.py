@@ -36,7 +36,8 @@ class Request:
 class ContinuousBatcher:
     """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
 
-    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: Optional[int] = 2, prefetch: int = 0):
+    def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: Optional[int] = 2, prefetch: int = 0,
+                 tower_steps_per_page: int = 48):
         self.engine = engine
         self.chunk = max(1, int(chunk))
         # free KV pages kept per running sequence when admitting (see plan_admission).  None = FULL RESERVATION: a sequence is admitted only
@@ -49,6 +50,8 @@ class ContinuousBatcher:
         # only, no tower in the decode loop's way — as soon as it has the slots and pages.  1 suits requests that finish at different
         # times (a slot is refilled as soon as it frees), n_slots suits closed sets of equal length.  0 = off.
         self.prefetch = max(0, int(prefetch)) if hasattr(engine, "vit_prefetch") else 0
+        # decode steps that pass while ONE page's tower runs on the side partition (A4 on 160-192 CUs: ~150 ms against 2.6-3.3 ms per step)
+        self.tower_steps_per_page = max(1, int(tower_steps_per_page))
         self._ahead: List[Tuple[int, Request]] = []             # requests whose tower has been prefetched, in packed order
         self._ahead_keep = None                                  # their (device) pixels stay alive until the rows are taken
         self.n_slots = int(engine.max_batch)
@@ -210,10 +213,19 @@ class ContinuousBatcher:
             return
         total_pages = self.engine.kv_pool_info()[0] if hasattr(self.engine, "kv_pool_info") else 1 << 30
         group, patches, tokens, pages = [], 0, 0, 0
-        # A prefetched group goes in only as a whole, and nothing may overtake it: a group larger than the slots that are free or about to
-        # be (within two decode chunks of their cap) would hold freed slots idle while it waits for the rest — with uneven output lengths
-        # (the reference's max_new_tokens=24000) for a long time.  At least one, so that a full engine still hides the next tower.
-        cap = min(self.prefetch, self.n_slots, max(1, len(self.free_slots()) + self._soon_free()))
+        # A prefetched group goes in only as a whole, and nothing may overtake it: a group larger than the slots that are free — or will be
+        # by the time its tower is done — would hold freed slots idle while it waits for the rest; with uneven output lengths (the
+        # reference's max_new_tokens=24000) for a long time.  The tower of k pages lasts about k * tower_steps_per_page decode
+        # steps, so the group is the LARGEST k <= prefetch for which k slots are free or within that horizon (+ two chunks) of their caps:
+        # equal caps (a document's pages: everything finishes together) prefetch the whole next group while the current one decodes — the
+        # round-5 rule "free now or within two chunks" started ONE tower there and ran the other 31 at admission, nothing beside them
+        # (mixed64: 4.40 -> 4.00 pages/s, profiles/r05_mixed64_lookahead_regression.txt).  At least one, so that a full engine still
+        # hides the next tower.
+        cap = 1
+        for k in range(min(self.prefetch, self.n_slots), 1, -1):
+            if len(self.free_slots()) + self._soon_free(2 * self.chunk + k * self.tower_steps_per_page) >= k:
+                cap = k
+                break
         while self.pending and len(group) < cap:
             rid, req = self.pending[0]
             p, t = req.n_patches(), int(req.input_ids.shape[0])
@@ -236,9 +248,10 @@ class ContinuousBatcher:
             raise
         self._ahead, self._ahead_keep = group, keep
 
-    def _soon_free(self) -> int:
-        """running sequences within two decode chunks of their generation cap (lengths as of the last poll)"""
-        return sum(1 for s, (_, r) in self.running.items() if self._last_lens.get(s, 0) + 2 * self.chunk >= int(r.max_new_tokens))
+    def _soon_free(self, horizon: Optional[int] = None) -> int:
+        """running sequences within `horizon` decode steps (default: two chunks) of their generation cap (lengths as of the last poll)"""
+        horizon = 2 * self.chunk if horizon is None else horizon
+        return sum(1 for s, (_, r) in self.running.items() if self._last_lens.get(s, 0) + horizon >= int(r.max_new_tokens))
 
     # ------------------------------------------------------------------ main loop
     def _collect(self) -> List[Tuple[int, Request, np.ndarray]]:

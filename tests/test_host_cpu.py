@@ -764,7 +764,7 @@ def test_scheduler_keeps_failed_groups_findable_for_the_callers_error_handling()
             return super().vit_take()
     mk = lambda i: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), 20, tag=i)
     eng = Failing(lambda prompt: int(prompt[0]) + np.arange(64), max_batch=2, max_patches=100, max_prefill_tokens=64, max_seq_len=256)
-    cb = ContinuousBatcher(eng, chunk=4, prefetch=2)
+    cb = ContinuousBatcher(eng, chunk=4, prefetch=2, tower_steps_per_page=1)      # a tower as short as a decode step: the look-ahead horizon is two chunks
     for i in range(1, 5):
         cb.submit(mk(i))
     eng.fail_prefetch = True
@@ -860,6 +860,18 @@ def test_scheduler_look_ahead_group_is_capped_by_the_slots_that_are_or_will_soon
         cb.step(); steps += 1
         assert steps < 3
     assert sum(1 for _, r in cb.running.values() if r.tag in (1, 2, 3)) == 3
+    # equal caps (the pages of one document, EOS off): everything finishes together, so the WHOLE next group is prefetched while the
+    # current one decodes — k towers last k * tower_steps_per_page steps, and all k slots are free by then
+    eng2 = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(4096), max_batch=4, max_patches=100, max_prefill_tokens=64, max_seq_len=8192)
+    cb2 = ContinuousBatcher(eng2, chunk=4, prefetch=4, tower_steps_per_page=48)
+    for i in range(1, 9):
+        cb2.submit(mk(i, 150))
+    cb2.step()                                             # 1-4 admitted at length 0: 8 + 4 * 48 = 200 >= 150 steps to go -> all four towers ahead
+    assert len(cb2.running) == 4 and [r.tag for _, r in cb2._ahead] == [5, 6, 7, 8]
+    outs = []
+    while not cb2.idle:
+        outs += cb2.step()
+    assert sorted(r.tag for _, r, _ in outs) == list(range(1, 9)) and all(len(t) == 150 for _, _, t in outs)
 
 
 def test_first_contact_script_on_a_synthetic_checkpoint_directory(tmp_path):
