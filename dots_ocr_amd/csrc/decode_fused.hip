@@ -560,19 +560,6 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
             if (lane == 0) rstd_s[r] = rstd;
         }
     }
-    // ---- 3. this wave's K slice of every row: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7].  The raw fragments are
-    // requested BEFORE the barrier (their addresses do not need the statistics; the registers of the statistic rows are free now), and
-    // the epilogue waves' sincosf runs while they fly: the second round trip, the barrier wait and the trigonometry overlap.
-    bf16x8 xf[TT][NC];
-    u32x4 raw[TT][NC];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        const int r = min(16 * t + m, B - 1);
-#pragma unroll
-        for (int o = 0; o < NC; ++o) raw[t][o] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
     if (ew && rot) {                  // precise sincosf, as in dec_qkv_kernel
         sincosf((float)pos * fr0, &rs[0], &rc[0]);
@@ -580,10 +567,20 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
     }
     __syncthreads();
     TRACE(2);
+    // ---- 3. this wave's K slice of every row, normalised in registers: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7].
+    // (Requesting the raw fragments BEFORE the barrier — their addresses do not need the statistics — measured slower: 16.9 vs 15.7 us
+    // on the partition, 16.3 vs 14.3 on the whole chip, profiles/r05_decode_wide_second_pass.txt.)
+    bf16x8 xf[TT][NC];
     {
+        u32x4 raw[TT][NC];
         float rsd[TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) rsd[t] = rstd_s[min(16 * t + m, B - 1)];
+        for (int t = 0; t < TT; ++t) {
+            const int r = min(16 * t + m, B - 1);
+            rsd[t] = rstd_s[r];
+#pragma unroll
+            for (int o = 0; o < NC; ++o) raw[t][o] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
+        }
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
