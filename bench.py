@@ -646,9 +646,11 @@ def main():
                     rd["note"] = ("timed region = software-pipelined batches: most decode steps run on the decode partition beside the next batch's vision tower "
                                   "(half-chip launch plan); the step alone on the whole chip is in roofline_decode_sequential")
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
-                    if deep:                       # the PMC traffic figure was taken at 8 rows on the whole chip: it describes roofline_decode_sequential, not this step
-                        rd["traffic"] = None
-                        rd["traffic_unit"] = "not measured for the %d-row step (PMC traffic at B = 8: roofline_decode_sequential.traffic)" % rif
+                    if deep:                       # the B = 8 whole-chip figure describes roofline_decode_sequential; the 64-row partition step has its own PMC pass (round 5)
+                        rd["traffic"] = recorded("r05_decode_traffic_64rows.json", "traffic_bytes_per_decode_step") if rif == 64 and a.workload == "a4" else None
+                        rd["traffic_unit"] = ("bytes per decode step (PMC, 64 rows on the 64-CU partition plan, profiles/r05_decode_traffic_64rows.json: 1.24 x the "
+                                              "algorithmic bytes — gate|up and lm_head pass their weights through the L2s twice, once per pair of batch tiles)"
+                                              if rd["traffic"] else "not measured for the %d-row step (PMC traffic at B = 8: roofline_decode_sequential.traffic)" % rif)
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
             cv, cd = (256 - dec_cus, dec_cus) if overlap and not sliced else (256, 256)
