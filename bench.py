@@ -306,7 +306,8 @@ def main():
             # look-ahead: with EOS disabled and equal caps every slot finishes together, so the whole next group's towers are prefetched
             # round 4: the partition launch plan covers any row count, so the look-ahead now wins at 32 occupied slots (4.04 -> 4.26 pages/s
             # on one GPU, profiles/r04_bench_mixed64*.json) and is the default; DOTS_BENCH_PREFETCH=0 switches it off
-            cb = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots))))
+            ag = os.environ.get("DOTS_BENCH_ADMIT_GROUP")
+            cb = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots))), admit_group=int(ag) if ag else None)
             outs = cb.run(reqs)
             mixed_meter["decode_steps"] += cb.decode_steps
             mixed_meter["requests"].append([(len(r.input_ids), len(o)) for r, o in zip(reqs, outs)])

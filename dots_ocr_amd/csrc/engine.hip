@@ -1298,6 +1298,19 @@ int dots_vit_prefetch(DotsEngine* e, const float* pixel_values, int on_device, i
     return DOTS_OK;
 }
 
+int dots_vit_prefetch_ready(DotsEngine* e, int* ready) {
+    if (!e || !ready) return e ? e->fail(DOTS_E_INVALID, "null argument") : DOTS_E_INVALID;
+    if (!e->pref_pending) return e->fail(DOTS_E_STATE, "no prefetched vision batch (dots_vit_prefetch)");
+    CK(hipSetDevice(e->device));
+    *ready = 0;
+    if (e->pref_deferred) return DOTS_OK;                 // not launched yet: it starts behind the next prefill
+    const hipError_t q = hipEventQuery(e->ev_vis_ready);
+    if (q == hipSuccess) *ready = 1;
+    else if (q == hipErrorNotReady) (void)hipGetLastError();      // must not stay behind as the thread's last error
+    else CK(q);
+    return DOTS_OK;
+}
+
 int dots_vit_take_prefetched(DotsEngine* e) {
     if (!e) return DOTS_E_INVALID;
     if (!e->pref_pending) return e->fail(DOTS_E_STATE, "no prefetched vision batch (dots_vit_prefetch)");

@@ -67,6 +67,7 @@ def _prototypes(lib):
         "dots_vit_forward": (i32, [vp, vp, i32, i64, P(i64), i32, vp]),
         "dots_vit_prefetch": (i32, [vp, vp, i32, i64, P(i64), i32, i32]),
         "dots_vit_take_prefetched": (i32, [vp]),
+        "dots_vit_prefetch_ready": (i32, [vp, P(i32)]),
         "dots_prefill": (i32, [vp, P(i32), P(i32), i32]),
         "dots_decode_step": (i32, [vp]),
         "dots_generate": (i32, [vp, P(i32), P(i32), i32, vp, i32, i64, P(i64), i32, i32, P(i32), i32, P(i32), P(i32)]),
@@ -120,7 +121,7 @@ def _prototypes(lib):
 
 EXPORTED_SYMBOLS = [
     "dots_create", "dots_destroy", "dots_last_error", "dots_stream", "dots_load_weight", "dots_finalize_weights",
-    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_set_gemm_plan", "dots_tower_tail", "dots_get_logits",
+    "dots_vit_forward", "dots_vit_prefetch", "dots_vit_take_prefetched", "dots_vit_prefetch_ready", "dots_preprocess_image", "dots_prefill", "dots_decode_step", "dots_generate", "dots_set_sampling", "dots_set_decode_plan", "dots_set_gemm_plan", "dots_tower_tail", "dots_get_logits",
     "dots_set_eos", "dots_slots_prefill", "dots_slots_decode", "dots_slots_poll", "dots_slot_read", "dots_slot_release", "dots_kv_pool_info", "dots_slot_capacity", "dots_slots_reset",
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
@@ -267,6 +268,12 @@ class Engine:
     def vit_take(self):
         """Put the prefetched vision rows in place for the next prefill / generate(..., vision_taken=True)."""
         self._ck(self.lib.dots_vit_take_prefetched(self.h), "dots_vit_take_prefetched")
+
+    def vit_ready(self) -> bool:
+        """True when the prefetched tower has finished: vit_take() then makes nothing wait (a serving loop keeps decoding until then)."""
+        r = C.c_int32(0)
+        self._ck(self.lib.dots_vit_prefetch_ready(self.h, C.byref(r)), "dots_vit_prefetch_ready")
+        return bool(r.value)
 
     def preprocess_image(self, rgb, out_dev: int, min_pixels: Optional[int] = None, max_pixels: Optional[int] = None,
                          shape: Optional[Sequence[int]] = None):

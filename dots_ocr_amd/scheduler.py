@@ -37,7 +37,7 @@ class ContinuousBatcher:
     """submit() requests at any time, call step() in a loop (or run() for a closed set)."""
 
     def __init__(self, engine, eos_ids: Sequence[int] = (), chunk: int = 16, headroom_pages: Optional[int] = 2, prefetch: int = 0,
-                 tower_steps_per_page: int = 48):
+                 tower_steps_per_page: int = 48, admit_group: Optional[int] = None):
         self.engine = engine
         self.chunk = max(1, int(chunk))
         # free KV pages kept per running sequence when admitting (see plan_admission).  None = FULL RESERVATION: a sequence is admitted only
@@ -52,6 +52,11 @@ class ContinuousBatcher:
         self.prefetch = max(0, int(prefetch)) if hasattr(engine, "vit_prefetch") else 0
         # decode steps that pass while ONE page's tower runs on the side partition (A4 on 160-192 CUs: ~150 ms against 2.6-3.3 ms per step)
         self.tower_steps_per_page = max(1, int(tower_steps_per_page))
+        # at most this many requests per ORDINARY admission (None: as many as fit).  With look-ahead on, the ordinary path only runs when
+        # nothing is prefetched — the cold start of a queue: admitting `prefetch`-sized groups there too starts the decode loop after ONE
+        # small tower instead of after the towers of every free slot, and the later groups' towers run beside it (a closed set of equal
+        # caps then also finishes staggered, one group per tower, instead of all at once with nothing left to overlap)
+        self.admit_group = None if admit_group is None else max(1, int(admit_group))
         self._ahead: List[Tuple[int, Request]] = []             # requests whose tower has been prefetched, in packed order
         self._ahead_keep = None                                  # their (device) pixels stay alive until the rows are taken
         self.n_slots = int(engine.max_batch)
@@ -128,7 +133,7 @@ class ContinuousBatcher:
         free = self.free_slots()
         group, patches, tokens = [], 0, 0
         pages_free = self.engine.kv_pool_info()[1] if hasattr(self.engine, "kv_pool_info") else 1 << 30
-        while self.pending and free:
+        while self.pending and free and (self.admit_group is None or len(group) < self.admit_group):
             rid, req = self.pending[0]
             p, t = req.n_patches(), int(req.input_ids.shape[0])
             if group and (patches + p > self.max_patches or tokens + t > self.max_prefill_tokens):
@@ -186,6 +191,10 @@ class ContinuousBatcher:
         """The group whose tower was prefetched goes in as a whole as soon as it has the slots and the pages."""
         free = self.free_slots()
         if len(free) < len(self._ahead):
+            return False
+        # sequences are decoding and the tower is still running: taking the group now would queue every decode chunk behind the tower
+        # (vit_take makes the engine's stream wait for it) — keep decoding, take it when its rows exist.  Nothing running: wait for it.
+        if self.running and hasattr(self.engine, "vit_ready") and not self.engine.vit_ready():
             return False
         if hasattr(self.engine, "kv_pool_info"):
             need = sum(self._admit_pages(int(r.input_ids.shape[0]), r.max_new_tokens) for _, r in self._ahead)

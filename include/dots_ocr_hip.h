@@ -124,6 +124,10 @@ int dots_vit_forward(DotsEngine* e, const float* pixel_values, int pixel_values_
 int dots_vit_prefetch(DotsEngine* e, const float* pixel_values, int pixel_values_on_device, int64_t total_patches,
                       const int64_t* grid_thw_host, int n_img, int after_prefill);
 int dots_vit_take_prefetched(DotsEngine* e);
+/* *ready = 1 when the tower of the prefetched batch has finished (dots_vit_take_prefetched then makes nothing wait), 0 while it runs or has
+ * not been launched yet (after_prefill).  A serving loop polls it between decode chunks and takes the batch only when its rows exist, so
+ * that the sequences already decoding never queue behind a tower (dots_ocr_amd/scheduler.py).  DOTS_E_STATE without a pending prefetch. */
+int dots_vit_prefetch_ready(DotsEngine* e, int* ready);
 
 /* Replaces prepare_inputs_embeds + the prefill forward of Qwen2ForCausalLM.
  * Packed prompts: input_ids int32 [sum(prompt_lens)] (host), slot i of the batch gets prompt i.

@@ -874,6 +874,46 @@ def test_scheduler_look_ahead_group_is_capped_by_the_slots_that_are_or_will_soon
     assert sorted(r.tag for _, r, _ in outs) == list(range(1, 9)) and all(len(t) == 150 for _, _, t in outs)
 
 
+def test_scheduler_cold_start_ramp_and_tower_readiness_gate():
+    """Round 5: admit_group = the look-ahead group size also for the ordinary (cold-start) admission, and a prefetched group is taken only
+    when its tower has FINISHED while sequences are decoding (Engine.vit_ready): the decode loop starts after one small tower, the later
+    groups' towers run beside it, no decode chunk ever queues behind a tower — and a closed set of equal caps finishes staggered."""
+    from fakes import FakeSlotEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+
+    class Timed(FakeSlotEngine):
+        tower_chunks = 3                                   # decode chunks a prefetched tower lasts
+        def vit_prefetch(self, *a, **k):
+            self._age = 0
+            return super().vit_prefetch(*a, **k)
+        def slots_decode(self, n):
+            self._age = getattr(self, "_age", 0) + 1
+            return super().slots_decode(n)
+        def vit_ready(self):
+            return self._age >= self.tower_chunks
+        def vit_take(self):
+            assert self._age >= self.tower_chunks or not self.slots, "a group was taken while its tower was running beside decoding sequences"
+            return super().vit_take()
+    mk = lambda i: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), 64, tag=i)
+    eng = Timed(lambda prompt: int(prompt[0]) + np.arange(4096), max_batch=8, max_patches=1000, max_prefill_tokens=640, max_seq_len=8192)
+    cb = ContinuousBatcher(eng, chunk=4, prefetch=2, admit_group=2, tower_steps_per_page=8)
+    for i in range(1, 13):
+        cb.submit(mk(i))
+    outs, occupancy = [], []
+    while not cb.idle:
+        outs += cb.step()
+        occupancy.append(len(cb.running))
+    kinds = [k for k, *_ in eng.log]
+    assert kinds[:3] == ["vit", "prefill", "prefetch"] and eng.log[0][1] == 2 * 16      # the cold start admits ONE group of two pages
+    # between a prefetch and its take there are >= tower_chunks decode chunks: the running sequences kept decoding beside the tower
+    for i, k in enumerate(kinds):
+        if k == "take":
+            j = max(x for x in range(i) if kinds[x] == "prefetch")
+            assert kinds[j:i].count("decode") >= Timed.tower_chunks
+    assert occupancy[0] == 2 and max(occupancy) >= 6                                    # the engine fills group by group
+    assert sorted(r.tag for _, r, _ in outs) == list(range(1, 13)) and all(len(t) == 64 for _, _, t in outs)
+
+
 def test_first_contact_script_on_a_synthetic_checkpoint_directory(tmp_path):
     """tools/first_contact.py — the one command for the day a real checkpoint is present — run end to end on CPU
     (--no-gpu: config diff against SURVEY §8(a)'s [RECALLED] table, safetensors inventory against what the engine consumes, text side,
