@@ -228,7 +228,9 @@ def main():
         raise SystemExit("--rows-in-flight must be a multiple of --batch, at most 64 (the engine's sequence slots)")
     n_groups = rif // B if deep else 1
     if mixed:
-        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "96")      # look-ahead towers on 160 CUs beside up to 32 decoding rows on 96
+        # look-ahead towers on 192 CUs beside up to 32 decoding rows on 64 (round 5, with the wide decode kernels: 4.92 pages/s against 4.68 at
+        # 96 / 160, profiles/r05_partition_sizes_highres_mixed64.txt; round 4: 96)
+        os.environ.setdefault("DOTS_OCR_OVERLAP_DEC_CUS", "64")
     if deep and not sliced:
         # measured (profiles/r04_deep_sweep.txt; decode CUs / rows in flight): a4 64 / 64 5.12 pages/s (tower 1 358 ms on 192 CUs, decode 1 418 ms; 5.34-5.43 with two batch tiles per workgroup in gate|up / lm_head: decode 1 270 ms), 64 / 32 4.93,
         # 96 / 32 4.95, 96 / 64 4.93, one batch on 128 / 128 4.11-4.21; highres 128 / 64 10.4 (11.5 with the two-tile kernels), 128 / 32 9.0, 128 / 16 7.3, 96 / 32 8.1
@@ -562,7 +564,7 @@ def main():
             dec_bytes = mm["decode_steps"] * Wb + kv_bytes
             attn_tf = mm["attn_flops"] / (mm["attn_ms"] / 1e3) / 1e12 if mm["attn_ms"] > 0 else 0.0
             dec_gbs = dec_bytes / (mm["decode_ms"] / 1e3) / 1e9 if mm["decode_ms"] > 0 else 0.0
-            dec_cus_m = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "96")) // 8 * 8
+            dec_cus_m = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "64")) // 8 * 8
             res["roofline"] = {"bound": "mfma", "kernel": "flash_attn64_kernel (ViT bidirectional var-len attention) over the timed region's towers: ragged packed batches of the six page sizes",
                                "achieved": attn_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / PEAK_BF16_TFLOPS, "traffic": None,
                                "algorithmic_flops": mm["attn_flops"], "launches": mm["attn_launches"], "towers": mm["towers"],
