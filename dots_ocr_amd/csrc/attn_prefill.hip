@@ -27,6 +27,7 @@
 // buffers (96 KB), tile t staged by the early half during its iteration t-1 and by the late half during t-2.  Together
 // with the explicit LDS look-ahead of the MFMA block: 1099 -> 1163 TFLOP/s (same-box A/B, profiles/r01_final2_*);
 // either change alone gains nothing.  Bit-identical results (same accumulation order).
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
 
@@ -392,9 +393,12 @@ template <int N, class F> DEVI void static_for(F&& f) { static_for_impl(std::mak
 __global__ __launch_bounds__(256) void flash_attn64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
     bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
-    float scale_log2e) {
+    float scale_log2e, XcdPlan plan) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // K ring | V^T ring
-    const QBlock qb = blocks[xcd_remap(blockIdx.x, n_items)];
+    // this XCD's chunk of the work list, cut by cost (kernels.h: XcdPlan); workgroups past the chunk have nothing to do
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (idx >= plan.cnt[xcd]) return;
+    const QBlock qb = blocks[plan.base[xcd] + idx];
     const int h = qb.head, hkv = h / group, n = qb.n;
     const int tid = threadIdx.x, l = tid & 63, l31 = l & 31, hi = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -670,9 +674,32 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
 
 }  // namespace
 
+XcdPlan make_xcd_plan(const QBlock* b, int n_blocks) {
+    XcdPlan p;
+    bool uniform = true;
+    for (int i = 1; i < n_blocks && uniform; ++i) uniform = b[i].n == b[0].n;
+    if (uniform || n_blocks < 8) {                               // equal costs: exactly xcd_remap's chunks
+        const int q = n_blocks / 8, r = n_blocks % 8;
+        for (int x = 0, pos = 0; x < 8; ++x) { p.base[x] = pos; p.cnt[x] = q + (x < r ? 1 : 0); pos += p.cnt[x]; }
+        return p;
+    }
+    auto cost = [&](int i) { return (int64_t)(((b[i].n + 63) / 64 + 1) & ~1); };      // KV tiles of the block's sequence (walked in pairs)
+    int64_t total = 0;
+    for (int i = 0; i < n_blocks; ++i) total += cost(i);
+    int pos = 0;
+    int64_t done = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int64_t target = total * (x + 1) / 8;              // prefix-sum split: chunk x ends where the running cost passes (x + 1) / 8
+        p.base[x] = pos;
+        while (pos < n_blocks && (x == 7 || done + cost(pos) / 2 < target)) done += cost(pos++);
+        p.cnt[x] = pos - p.base[x];
+    }
+    return p;
+}
+
 hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                              const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
-                             int causal, float scale) {
+                             int causal, float scale, const XcdPlan* plan) {
     if (n_blocks <= 0) return hipSuccess;
     if (Hq % Hkv != 0) return hipErrorInvalidValue;
     const float c = scale * 1.44269504088896340736f;
@@ -701,7 +728,15 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
                 if (e != hipSuccess) return e;
                 __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
             }
-            hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c);
+            XcdPlan pl;
+            if (plan) pl = *plan;
+            else {                                               // no plan from the caller: xcd_remap's equal-count chunks
+                const int qn = n_blocks / 8, rn = n_blocks % 8;
+                for (int x = 0, pos = 0; x < 8; ++x) { pl.base[x] = pos; pl.cnt[x] = qn + (x < rn ? 1 : 0); pos += pl.cnt[x]; }
+            }
+            int mx = 0;
+            for (int x = 0; x < 8; ++x) mx = std::max(mx, (int)pl.cnt[x]);
+            hipLaunchKernelGGL(flash_attn64_kernel, dim3(8 * mx), dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c, pl);
             return hipGetLastError();
         }
         if (mode >= 1) return causal ? go(flash_attn_kernel<true, 8, 1>, 512, 3 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 1>, 512, 3 * BUF_BYTES);

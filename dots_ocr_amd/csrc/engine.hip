@@ -726,6 +726,7 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
     CK(launch_rope_table(s, e->v_pos, e->v_inv_freq, e->v_cs, N, 1));
     const float scale = 1.0f / sqrtf(128.0f);
     e->attn_pairs = 0;
+    const XcdPlan xcd_plan = make_xcd_plan(e->h_qblocks.data(), (int)e->h_qblocks.size());      // the XCDs' chunks of the attention work list, cut by cost
     // a prefetched tower: its last e->tail_now blocks and the merger run on the unmasked stream (DotsEngine::s_vit_full)
     hipStream_t const s_first = s;
     const bool prefetched = e->s_vit && s == e->s_vit && e->s_vit_full;
@@ -743,7 +744,7 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
         RET(vdense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
         CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
         CK(attn_event(e, 2 * i));
-        CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale));
+        CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale, &xcd_plan));
         CK(attn_event(e, 2 * i + 1));
         e->attn_pairs = i + 1;
         RET(vdense(e, e->v_att, L.proj_w, L.proj_8, L.proj_s, L.proj_b, e->v_x, e->v_x, N, E, E, E, EPI_RESIDUAL));
@@ -1882,7 +1883,8 @@ int dots_op_flash_attn(DotsEngine* e, const void* q, const void* k, const void* 
     int64_t Tpad = 0;
     RET(upload_lists(e, cu, n_seq, Hq, tiles, qb, &dt, &dq, &Tpad));
     const int64_t T = cu[n_seq];
-    hipError_t r = launch_flash_attn(e->stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, dq, (int)qb.size(), T, Tpad, Hq, Hkv, causal, scale);
+    const XcdPlan xcd_plan = make_xcd_plan(qb.data(), (int)qb.size());
+    hipError_t r = launch_flash_attn(e->stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, dq, (int)qb.size(), T, Tpad, Hq, Hkv, causal, scale, &xcd_plan);
     hipStreamSynchronize(e->stream);
     e->release(dt);
     e->release(dq);

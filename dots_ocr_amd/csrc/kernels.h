@@ -40,9 +40,16 @@ hipError_t launch_gather_rows(hipStream_t s, const bf16_t* x, const int32_t* row
 // the XCD-contiguous remap of the 1-D grid gives one XCD (one L2) all query blocks that stream the same K/V.
 struct QBlock { int32_t q0, n, tok0, pad0, head, _pad; };   // first row in seq, seq length, packed token offset, padded V^T offset
 int flash_rows_per_block();      // 128 or 256 query rows per QBlock work item (what build_worklists must use)
+// Which contiguous chunk of the QBlock list each XCD walks (workgroup i runs on XCD i % 8 and takes item base[i % 8] + i / 8; workgroups past
+// cnt[] exit at once).  xcd_remap's chunks hold equal COUNTS; a block costs its sequence's KV tiles, so on a ragged batch (mixed page
+// sizes) equal counts gave one XCD 1.32 x the mean work while the others idled (round 5, mixed64's towers).  make_xcd_plan cuts the list
+// by COST instead (prefix-sum split: chunks stay contiguous, so the blocks of a (sequence, head) still share an L2); equal lengths give
+// xcd_remap's chunks exactly.  nullptr = xcd_remap.
+struct XcdPlan { int32_t base[8], cnt[8]; };
+XcdPlan make_xcd_plan(const QBlock* blocks_host, int n_blocks);
 hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out,
                              const QBlock* blocks, int n_blocks, int64_t T, int64_t Tpad, int Hq, int Hkv,
-                             int causal, float scale);
+                             int causal, float scale, const XcdPlan* plan = nullptr);
 
 // ---- decode.hip  (KV page pool layout documented there)
 hipError_t launch_kv_to_pages(hipStream_t s, const bf16_t* k, const bf16_t* qkv, const Tile64* tiles, int n_tiles,
