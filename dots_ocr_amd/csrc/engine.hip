@@ -1892,6 +1892,25 @@ int dots_op_flash_attn(DotsEngine* e, const void* q, const void* k, const void* 
     return DOTS_OK;
 }
 
+int dots_plan_flash_xcd(const int32_t* lens, int n_seq, int Hq, int32_t* base8, int32_t* cnt8, int64_t* cost8) {
+    if (!lens || n_seq < 1 || Hq < 1 || !base8 || !cnt8 || !cost8) return DOTS_E_INVALID;
+    std::vector<int> L(lens, lens + n_seq);
+    for (int n : L)
+        if (n < 1) return DOTS_E_INVALID;
+    std::vector<Tile64> tiles;
+    std::vector<QBlock> qb;
+    int64_t Tpad = 0;
+    build_worklists(L, Hq, tiles, qb, &Tpad);
+    const XcdPlan p = make_xcd_plan(qb.data(), (int)qb.size());
+    for (int x = 0; x < 8; ++x) {
+        base8[x] = p.base[x];
+        cnt8[x] = p.cnt[x];
+        cost8[x] = 0;
+        for (int i = p.base[x]; i < p.base[x] + p.cnt[x]; ++i) cost8[x] += ((qb[i].n + 63) / 64 + 1) & ~1;
+    }
+    return (int)qb.size();
+}
+
 int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, void* vt, const int32_t* cu, int n_seq,
                            const int32_t* pos_host, int Hq, int Hkv, int rope2d, float theta) {
     if (!e || !cu || n_seq < 1 || !pos_host) return DOTS_E_INVALID;

@@ -102,6 +102,7 @@ def _prototypes(lib):
         "dots_op_quant_fp8": (i32, [vp, vp, vp, i64, i32]),
         "dots_op_gemm_fp8": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]),
         "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
+        "dots_plan_flash_xcd": (i32, [P(i32), i32, i32, P(i32), P(i32), P(i64)]),
         "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
         "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32]),
         "dots_op_decode_attn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32]),
@@ -126,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8", "dots_op_gemm_fp8",
-    "dots_op_flash_attn", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
+    "dots_op_flash_attn", "dots_plan_flash_xcd", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
     "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
 
@@ -145,6 +146,19 @@ def c_config(cfg: DotsConfig, max_batch: int, max_seq_len: int, max_patches: int
         v_ln_eps=v.merger_ln_eps, v_use_bias=int(v.use_bias), v_post_norm=int(v.post_norm),
         max_batch=max_batch, max_seq_len=max_seq_len, max_patches=max_patches,
         max_prefill_tokens=max_prefill_tokens, kv_pool_tokens=kv_pool_tokens, fp8_weights=int(bool(fp8_weights)))
+
+
+def plan_flash_xcd(lens: Sequence[int], heads: int):
+    """Host-only: (base[8], cnt[8], cost[8], n_items) — how the flash-attention work list of a packed batch of sequences of `lens` patches
+    is cut across the XCDs (dots_plan_flash_xcd: equal KV-tile cost per XCD).  Needs the library, not a GPU."""
+    lib = _lib.load()
+    _prototypes(lib)
+    L = np.ascontiguousarray(lens, dtype=np.int32)
+    base, cnt, cost = np.zeros(8, np.int32), np.zeros(8, np.int32), np.zeros(8, np.int64)
+    n = lib.dots_plan_flash_xcd(_i32p(L), int(L.shape[0]), int(heads), _i32p(base), _i32p(cnt), _i64p(cost))
+    if n < 0:
+        raise DotsEngineError(f"dots_plan_flash_xcd failed ({n})")
+    return base, cnt, cost, int(n)
 
 
 def _i32p(a: np.ndarray):

@@ -266,6 +266,11 @@ int dots_op_gemm_fp8(DotsEngine* e, const void* A_dev, const void* W_dev, const 
  * out bf16 [T, Hq*128]. */
 int dots_op_flash_attn(DotsEngine* e, const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                        const int32_t* cu_seqlens_host, int n_seq, int Hq, int Hkv, int causal, float scale);
+/* Host-only (no device, no engine): how the flash-attention work list of a packed batch of sequences of lens[0 .. n_seq) patches and Hq heads
+ * is cut across the 8 XCDs — base8[x] / cnt8[x] = the contiguous chunk of (sequence, head, query block) items XCD x walks, cost8[x] = its KV
+ * tiles (csrc/kernels.h: XcdPlan; equal COST per XCD, not equal count: tests/test_cabi_cpu.py checks the balance on BASELINE configs[3]'s
+ * page mix).  Returns the number of items, or a negative DOTS_E_*. */
+int dots_plan_flash_xcd(const int32_t* lens, int n_seq, int Hq, int32_t* base8, int32_t* cnt8, int64_t* cost8);
 /* Splits a packed qkv GEMM output [T, (Hq+2*Hkv)*128] into rope'd q/k and transposed v in the
  * layouts dots_op_flash_attn consumes.  rope2d != 0: vision 2-D rope from pos [T,2] int32;
  * else 1-D rope with positions pos [T] int32 and base theta. */

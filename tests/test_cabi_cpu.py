@@ -90,3 +90,39 @@ def test_no_kernel_spills_registers_or_uses_scratch():
             if m:
                 assert int(m.group(2)) == 0, f"{rep.name}: {name}: {m.group(1)} = {m.group(2)}"
     assert kernels >= 40
+
+
+def test_flash_work_list_is_cut_by_cost_across_the_xcds():
+    """Round 5 (csrc/kernels.h: XcdPlan), host logic through the C ABI, no GPU: workgroup i of the flash-attention launch runs on XCD i % 8 and
+    walks that XCD's contiguous chunk of the (sequence, head, query block) list.  Equal-COUNT chunks (rounds 1-4) are equal work only for
+    equal lengths; on the page mix of BASELINE configs[3] one XCD carried 1.32 x the mean.  The plan must (a) cover every item exactly once
+    in order, (b) give every XCD the same KV-tile cost within 1 %, (c) reproduce the equal-count chunks for equal lengths."""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import numpy as np
+    import bench
+    from dots_ocr_amd import build, dp
+    from dots_ocr_amd.engine import plan_flash_xcd
+    from dots_ocr_amd.image_utils import smart_resize
+    build.build(verbose=False)
+    patches = []
+    for w, h in bench.mixed_pages(64):
+        rh, rw = smart_resize(h, w)
+        patches.append((rh // 14) * (rw // 14))
+    order = dp.shard_pages([dp.page_cost(p, 1024) for p in patches], 1)[0]
+    lens = [patches[i] for i in order]
+    for tower in (lens[:32], lens[32:], lens[:5], [39648, 1680, 1680, 1680]):
+        base, cnt, cost, n = plan_flash_xcd(tower, 12)
+        assert n == sum(12 * -(-m // 256) for m in tower)
+        assert base[0] == 0 and int(cnt.sum()) == n and all(base[x + 1] == base[x] + cnt[x] for x in range(7))
+        if len(tower) >= 5:
+            assert cost.max() <= 1.01 * cost.mean(), (cost.tolist(), "an XCD carries more than 1 % above the mean work")
+        # what equal counts would have given: the imbalance the plan removes (>= 1.25 x on the two 32-page towers of the bench)
+        per_item = np.concatenate([np.full(12 * -(-m // 256), ((-(-m // 64)) + 1) & ~1) for m in tower])
+        eq = [per_item[x * n // 8:(x + 1) * n // 8].sum() for x in range(8)]
+        if len(tower) == 32:
+            assert max(eq) >= 1.25 * np.mean(eq)
+    base, cnt, cost, n = plan_flash_xcd([19824] * 8, 12)            # the a4 batch: exactly the equal-count chunks (one sequence per XCD)
+    assert n == 7488 and cnt.tolist() == [936] * 8 and base.tolist() == [936 * x for x in range(8)] and len(set(cost.tolist())) == 1
+    base, cnt, cost, n = plan_flash_xcd([300], 2)                   # fewer items than XCDs
+    assert n == 4 and cnt.tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
