@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
+SVG_CHART = (588, 560)         # demo/demo_image2.png-sized chart input
 N_TEXT_TOKENS = 241            # BPE length of the chat template around prompt_layout_all_en (T = 4956 + ~244)
 
 # BASELINE configs[3] / SURVEY §8(d) config 4: empirical fixture distribution of page sizes (width, height), seed 2025
@@ -146,6 +147,30 @@ def cpu_baseline(cfg, sd_bf16, cores, page, ids, max_new_tokens):
             "raw_seconds": {k: ([round(x, 3) for x in v] if isinstance(v, list) else round(v, 4)) for k, v in raw.items()}}
 
 
+def bench_prompt_ids(proc, cfg, messages, n_vis, page_no):
+    """chat template -> ids.  The stand-in byte tokenizer (no checkpoint tokenizer exists offline) makes ~4x more
+    tokens than BPE for the text part, so the text is clipped to the BPE-equivalent length: the prompt keeps the
+    BASELINE shape (3 + n_vis + 241 + ... = 5 200 tokens for an A4 page) while its tokenisation is really executed.
+    (Module level so that tools/make_a4_anchor.py and tests/test_a4_anchor_gpu.py build the very prompt the bench runs.)"""
+    from dots_ocr_amd.processing import IMG_PAD
+    text = proc.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+    head, tail = text.split(IMG_PAD)                           # "<|user|><|img|>" | "<|endofimg|>{prompt}<|endofuser|><|assistant|>"
+    h_ids, t_ids = proc.tokenizer.encode(head), proc.tokenizer.encode(tail)
+    rng = np.random.default_rng(page_no)                       # distinct prompts per page, like distinct documents
+    body = np.asarray(t_ids[1:-2][:N_TEXT_TOKENS - 2], np.int64)
+    body = (body + rng.integers(0, 200, len(body))) % 256      # still byte ids
+    return np.concatenate([h_ids, [cfg.image_token_id] * n_vis, t_ids[:1], body, t_ids[-2:]]).astype(np.int32)
+
+
+def bench_messages(workload="a4"):
+    prompts_json = json.loads((ROOT / "dots_ocr_amd" / "data" / "prompts.json").read_text())
+    if workload == "svg":
+        prompt_text = prompts_json["prompt_image_to_svg"].replace("{width}", str(SVG_CHART[0])).replace("{height}", str(SVG_CHART[1]))
+    else:
+        prompt_text = prompts_json["prompt_layout_all_en"]
+    return [{"role": "user", "content": [{"type": "image", "image": "page"}, {"type": "text", "text": prompt_text}]}]
+
+
 def mixed_pages(n_total, seed=2025):
     import random
     rng = random.Random(seed)
@@ -187,7 +212,6 @@ def main():
     from dots_ocr_amd.image_utils import smart_resize
     from dots_ocr_amd.processing import IMG_PAD, DotsOcrProcessor
     from dots_ocr_amd.synthetic import A4_200DPI, HIGH_RES, synth_page
-    SVG_CHART = (588, 560)                          # demo/demo_image2.png-sized chart input
     from dots_ocr_amd.weights import random_state_dict
 
     cfg = DotsConfig.tiny(layers=4, v_layers=4) if a.workload == "tiny" else DotsConfig()
@@ -240,12 +264,7 @@ def main():
                  max_prefill_tokens=slots * max_prompt + 64, fp8_weights=fp8)
     eng.load_state_dict(sd)
     proc = DotsOcrProcessor(cfg, engine=eng)
-    prompts_json = json.loads((ROOT / "dots_ocr_amd" / "data" / "prompts.json").read_text())
-    if a.workload == "svg":
-        prompt_text = prompts_json["prompt_image_to_svg"].replace("{width}", str(SVG_CHART[0])).replace("{height}", str(SVG_CHART[1]))
-    else:
-        prompt_text = prompts_json["prompt_layout_all_en"]
-    messages = [{"role": "user", "content": [{"type": "image", "image": "page"}, {"type": "text", "text": prompt_text}]}]
+    messages = bench_messages(a.workload)
 
     # inputs resident in HBM before the timed region: the uint8 pixels of every page; one fp32 patch buffer is reused
     page_arrays = [np.ascontiguousarray(np.asarray(p.convert("RGB"), dtype=np.uint8)) for p in pages]
@@ -263,16 +282,7 @@ def main():
     host_ms = {"tokenize_ms": 0.0, "preprocess_ms": 0.0, "detokenize_ms": 0.0}
 
     def tokenize(n_vis, page_no):
-        """chat template -> ids.  The stand-in byte tokenizer (no checkpoint tokenizer exists offline) makes ~4x more
-        tokens than BPE for the text part, so the text is clipped to the BPE-equivalent length: the prompt keeps the
-        BASELINE shape (3 + n_vis + 241 + ... = 5 200 tokens for an A4 page) while its tokenisation is really executed."""
-        text = proc.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
-        head, tail = text.split(IMG_PAD)                           # "<|user|><|img|>" | "<|endofimg|>{prompt}<|endofuser|><|assistant|>"
-        h_ids, t_ids = proc.tokenizer.encode(head), proc.tokenizer.encode(tail)
-        rng = np.random.default_rng(page_no)                       # distinct prompts per page, like distinct documents
-        body = np.asarray(t_ids[1:-2][:N_TEXT_TOKENS - 2], np.int64)
-        body = (body + rng.integers(0, 200, len(body))) % 256      # still byte ids
-        return np.concatenate([h_ids, [cfg.image_token_id] * n_vis, t_ids[:1], body, t_ids[-2:]]).astype(np.int32)
+        return bench_prompt_ids(proc, cfg, messages, n_vis, page_no)
 
     def preprocess_all():
         grids, off = [], 0

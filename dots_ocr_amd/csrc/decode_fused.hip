@@ -1130,8 +1130,9 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
 }
 
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
-                             int B, int H, int I, float eps, int part_cus) {
+                             int B, int H, int I, float eps, int part_cus, bf16_t* xn) {
     if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
+    if (xn && dec_stream64_supports(B, H)) return launch_dec_gateup64(s, h, ln_w, W13d, wscale, act, xn, B, H, I, eps, wide_cus(part_cus));      // round 6: four batch tiles per workgroup
     return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps, part_cus)
                   : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps, part_cus);
 }
@@ -1158,8 +1159,9 @@ static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
 }
 
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
-                             int B, int H, int V, float eps) {
+                             int B, int H, int V, float eps, int part_cus, bf16_t* xn) {
     if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
+    if (xn && dec_stream64_supports(B, H) && H % (32 * 8) == 0) return launch_dec_lmhead64(s, h, ln_w, Wd, wscale, logits, xn, B, H, V, eps, wide_cus(part_cus));
     return wscale ? lmhead_launch(s, h, ln_w, (const u32x2*)Wd, wscale, logits, B, H, V, eps)
                   : lmhead_launch(s, h, ln_w, (const bf16x8*)Wd, wscale, logits, B, H, V, eps);
 }

@@ -193,7 +193,7 @@ struct DotsEngine {
     float temperature = 0.f, top_p = 1.f;      // temperature <= 0: greedy (arg max)
     uint64_t seed = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
-    bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr;
+    bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_xn = nullptr;      // d_xn: normalised rows of batches above 32 rows (decode_b64.hip)
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     // decode launch plan forced on every step (dots_set_decode_plan): 0 = by stream (whole chip / CU partition), 1 = always the partition plan
     int force_part = 0;
@@ -569,6 +569,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_q, (size_t)mb * Nq));
     CK(e->alloc(&e->d_att, (size_t)mb * Nq));
     CK(e->alloc(&e->d_act, (size_t)mb * c.intermediate_size));
+    CK(e->alloc(&e->d_xn, (size_t)DOTS_MAX_BATCH * H));
     CK(e->alloc(&e->d_logits, (size_t)mb * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
@@ -1075,10 +1076,10 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale, part ? e->dec_cus : 0, e->attn_stream));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
         CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part ? e->dec_cus : 0));
-        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0));
+        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn));
         CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part ? e->dec_cus : 0));
     }
-    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps));
+    CK(launch_dec_lmhead(s, e->d_h, e->final_norm, e->lm_head_d, e->lm_head_s, e->d_logits, B, H, c.vocab_size, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn));
     e->B_sel = B;
     e->sel_now = e->d_sel;
     RET(select_tokens(e, 1));
@@ -2013,7 +2014,7 @@ int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const voi
     CK(sc.get(&act, (size_t)(B + 15) / 16 * 16 * I));
     CK(launch_pack_w13(e->stream, (const bf16_t*)gate_w, (const bf16_t*)up_w, w13, I, H));
     RET(op_weight(e, sc, w13, (int64_t)2 * I, H, 0, 0, false, fp8, &w13d, &wscale));
-    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps));
+    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps, e->force_part ? e->dec_cus : 0, e->d_xn));
     CK(launch_unpack_x(e->stream, act, (bf16_t*)act_out, B, I));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
@@ -2026,7 +2027,7 @@ int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const voi
     void* wd = nullptr;
     float* wscale = nullptr;
     RET(op_weight(e, sc, (const bf16_t*)w, V, H, 0, 0, false, fp8, &wd, &wscale));
-    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (float*)logits_out, B, H, V, eps));
+    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (float*)logits_out, B, H, V, eps, e->force_part ? e->dec_cus : 0, e->d_xn));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

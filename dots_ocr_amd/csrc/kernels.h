@@ -65,10 +65,18 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
 hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus = 0);   // h += X @ W^T
 // part_cus > 0 (all dense launchers): the stream is CU-masked to that many CUs.  qkv / proj: whole 16-row weight tiles per workgroup at B <= 16,
 // one round of wide workgroups above; gate|up: the grid is capped at what the CUs hold at once, the workgroups walk the (gate, up) tile pairs
+// xn: scratch for the normalised rows of batches above 32 rows (MAX_DECODE_ROWS x H bf16; decode_b64.hip) or nullptr = the round-4 two-tile kernels
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
-                             int B, int H, int I, float eps, int part_cus = 0);
+                             int B, int H, int I, float eps, int part_cus = 0, bf16_t* xn = nullptr);
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
-                             int B, int H, int V, float eps);
+                             int B, int H, int V, float eps, int part_cus = 0, bf16_t* xn = nullptr);
+// ---- decode_b64.hip (round 6): batches above 32 rows — all four 16-row batch tiles in one workgroup, every weight byte crosses a CU once
+bool dec_stream64_supports(int B, int H);
+hipError_t launch_dec_norm_ximg(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, bf16_t* xn, int B, int H, float eps);       // rows -> rmsnorm -> X image
+hipError_t launch_dec_gateup64(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act, bf16_t* xn,
+                               int B, int H, int I, float eps, int cus);
+hipError_t launch_dec_lmhead64(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits, bf16_t* xn,
+                               int B, int H, int V, float eps, int cus);
 int decode_attn_waves();                       // pages in flight per decode-attention workgroup (engine constant)
 int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,

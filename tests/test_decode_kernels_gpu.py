@@ -311,6 +311,48 @@ def test_two_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8):
         assert torch.equal(logits[r0:r0 + n].view(torch.int32), l1.view(torch.int32)), f"lm_head rows {r0}..{r0 + n - 1} of {B}"
 
 
+@pytest.mark.parametrize("cus", [None, 96, 64, 32])        # whole chip: 4 waves, deep ring; 96 CUs: 8 waves; 64: 12 waves, one round; 32: 12 waves, two rounds of gate|up
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B", [33, 40, 64])
+def test_four_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8, cus, monkeypatch):
+    """Round 6 (csrc/decode_b64.hip): above 32 rows gate|up and lm_head run ALL FOUR batch tiles in one workgroup — a norm kernel writes the
+    X image once, a wave owns a pair of weight tiles for all rows and walks K in order through an LDS ring of X chunks.  Per output element
+    the chains are the per-tile kernels' (four K slices summed in order / even + odd k-steps), so the rows of a B-row call must equal, bit
+    for bit, the same rows computed in calls of at most 16 rows, for every launch shape (waves per workgroup, ring depth, rounds)."""
+    if cus is None:
+        monkeypatch.delenv("DOTS_OCR_DEC_WIDE_CUS", raising=False)
+    else:
+        monkeypatch.setenv("DOTS_OCR_DEC_WIDE_CUS", str(cus))
+    g = torch.Generator().manual_seed(B * 13 + 7)
+    h, ln_w = bf(torch.randn(B, H, generator=g) * 3), bf(1 + 0.1 * torch.randn(H, generator=g))
+    gate, up = bf(torch.randn(I, H, generator=g) / math.sqrt(H)), bf(torch.randn(I, H, generator=g) / math.sqrt(H))
+    W = bf(torch.randn(V, H, generator=g) * 0.02)
+    hd, lnd, gd, ud, Wd_ = dev(h), dev(ln_w), dev(gate), dev(up), dev(W)
+    act = torch.zeros(B, I, dtype=torch.bfloat16, device="cuda")
+    logits = torch.zeros(B, V, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.op_dec_gateup(hd.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), act.data_ptr(), B, H, I, EPS, fp8=fp8)
+    eng.op_dec_lmhead(hd.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), logits.data_ptr(), B, H, V, EPS, fp8=fp8)
+    eng.synchronize()
+    assert float(act.float().abs().max()) > 0 and float(logits.abs().max()) > 0
+    assert torch.isfinite(act.float()).all() and torch.isfinite(logits).all()
+    monkeypatch.delenv("DOTS_OCR_DEC_WIDE_CUS", raising=False)
+    for r0 in range(0, B, 16):
+        n = min(16, B - r0)
+        hs = hd[r0:r0 + n].contiguous()
+        a1 = torch.zeros(n, I, dtype=torch.bfloat16, device="cuda")
+        l1 = torch.zeros(n, V, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.op_dec_gateup(hs.data_ptr(), lnd.data_ptr(), gd.data_ptr(), ud.data_ptr(), a1.data_ptr(), n, H, I, EPS, fp8=fp8)
+        eng.op_dec_lmhead(hs.data_ptr(), lnd.data_ptr(), Wd_.data_ptr(), l1.data_ptr(), n, H, V, EPS, fp8=fp8)
+        eng.synchronize()
+        assert torch.equal(act[r0:r0 + n].view(torch.int16), a1.view(torch.int16)), f"gate|up rows {r0}..{r0 + n - 1} of {B}"
+        assert torch.equal(logits[r0:r0 + n].view(torch.int32), l1.view(torch.int32)), f"lm_head rows {r0}..{r0 + n - 1} of {B}"
+    if cus is None and not fp8:       # and against the oracle (the <= 16-row kernels are held to it above; this is the same check on the new path)
+        ref = om.rms_norm(h.float(), ln_w.float(), EPS, True) @ W.float().t()
+        close(logits, ref, rel=1e-4, abs_=1e-3, what="logits of the four-tile lm_head")
+
+
 @pytest.mark.parametrize("cus", [None, 100, 64, 48])       # CUs the launcher plans for: whole chip (1 unit / 1 tile per workgroup), 2 units, 3 units / 2 tiles, 4 units
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("B", [17, 33, 40, 64])

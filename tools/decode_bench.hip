@@ -24,6 +24,7 @@ static hipStream_t S;
 #ifdef DOTS_TRACE
 void dots_trace_set_fused(unsigned long long* buf);
 void dots_trace_set_decode(unsigned long long* buf);
+void dots_trace_set_b64(unsigned long long* buf);
 static unsigned long long* g_trace = nullptr;
 constexpr size_t TRACE_WORDS = (size_t)4096 * 16 * 8;
 // per-slot statistics of the LAST launch that wrote the trace buffer: offsets in us from the earliest slot-0 stamp
@@ -91,6 +92,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(g_trace, 0, TRACE_WORDS * 8));
     dots_trace_set_fused(g_trace);
     dots_trace_set_decode(g_trace);
+    dots_trace_set_b64(g_trace);
 #endif
     const int max_pages = (max_seq + 63) / 64;
     const int n_splits = decode_attn_splits(max_seq);
@@ -139,9 +141,10 @@ int main(int argc, char** argv) {
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale, part_cus)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
     auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, part_cus)); };
-    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus)); };
+    bf16_t* xn = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<bf16_t>((size_t)64 * H);      // scratch of the round-6 four-tile kernels (decode_b64.hip)
+    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus, xn)); };
     auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I, part_cus)); };
-    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps)); };
+    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps, part_cus, xn)); };
     // skip: bit mask of kernel kinds left out (marginal cost of a kind inside the real, HBM-cold step = full - skipped)
     auto step_skip = [&](int skip) {
         CK(launch_dec_embed(S, cur, embed, h0, B, H));

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/a4_anchor.npz: ONE full-depth pass of the CPU oracle (oracle/model.py: 42 vision blocks at 19 824 patches,
+28 LM layers over the 5 200-token bench prompt, 16 greedy steps) over synthetic A4 page 0 + the prompt bench.py gives page 0, in BOTH
+oracle modes, reduced to what a GPU test needs (VERDICT r5 "next" #4: whole-path parity at the benchmark size with no oracle time in the
+GPU suite).  Reference path restated by the oracle: dots_ocr/parser.py:99-116.
+
+    nice -n 10 python tools/make_a4_anchor.py [threads]        (≈ 20 min per mode on 8 cores; run in THIS container, output committed)
+
+Kept per mode (emulated-bf16 = the engine's rounding points, fp32 = truth for tolerances):
+  vis_rows[256]                the sampled merged-vision row indices (seeded), vis_<mode> their values, vis_absmax_<mode> the tensor's max |x|
+  tokens_emu[16], margins_emu  the emulated oracle's free-running greedy tokens and its top-2 margin at each step
+  then both modes TEACHER-FORCED on tokens_emu, per step s:
+  top_ids_<mode>[s, 32], top_vals_<mode>[s, 32]     the 32 largest logits
+  probe_ids[2048], probe_<mode>[s, 2048]            logits at a fixed seeded sample of the vocabulary
+  range_<mode>[s, 2]                                min / max logit (the 3 % rule's scale)
+plus prompt_ids (so that tokenizer drift cannot silently change the test input) and a checksum of the fp32 patch matrix."""
+import os
+import sys
+import time
+import zlib
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from dots_ocr_amd.config import DotsConfig  # noqa: E402
+from dots_ocr_amd.image_utils import preprocess_image  # noqa: E402
+from dots_ocr_amd.processing import DotsOcrProcessor  # noqa: E402
+from dots_ocr_amd.synthetic import A4_200DPI, synth_page  # noqa: E402
+from dots_ocr_amd.weights import random_state_dict  # noqa: E402
+from oracle import model as om  # noqa: E402
+
+N_STEPS, N_ROWS, N_TOP, N_PROBE = 16, 256, 32, 2048
+OUT = ROOT / "tests" / "golden" / "a4_anchor.npz"
+
+
+def main():
+    threads = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 8)
+    torch.set_num_threads(threads)
+    cfg = DotsConfig()
+    sd = random_state_dict(cfg, seed=0, threads=min(32, threads))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    del sd
+    page = synth_page(0, A4_200DPI)
+    pv, thw = preprocess_image(page)
+    ids = bench.bench_prompt_ids(DotsOcrProcessor(cfg), cfg, bench.bench_messages("a4"), pv.shape[0] // 4, 0)
+    rng = np.random.default_rng(20260930)
+    rows = np.sort(rng.choice(pv.shape[0] // 4, N_ROWS, replace=False)).astype(np.int32)
+    probe = np.sort(rng.choice(cfg.vocab_size, N_PROBE, replace=False)).astype(np.int32)
+    rec = {"prompt_ids": ids, "grid_thw": np.asarray(thw, np.int64), "pixel_crc32": np.asarray([zlib.crc32(pv.tobytes())], np.uint32),
+           "vis_rows": rows, "probe_ids": probe, "seconds": {}}
+    t_ids, t_pv, t_thw = torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(pv), torch.tensor([thw])
+    forced = None
+    secs = []
+    for mode, emu in (("emu", True), ("f32", False)):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            vis = om.vision_tower(sd32, cfg, t_pv, t_thw, emulate_bf16=emu)
+        t1 = time.perf_counter()
+        print(f"[{mode}] tower {t1 - t0:.0f} s", flush=True)
+        rec[f"vis_{mode}"] = vis[torch.from_numpy(rows.astype(np.int64))].numpy().astype(np.float32)
+        rec[f"vis_absmax_{mode}"] = np.asarray([float(vis.abs().max())], np.float32)
+        toks, logits = om.generate(sd32, cfg, t_ids, None, None, N_STEPS, emulate_bf16=emu, forced_tokens=forced, return_logits=True, vision_embeds=vis)
+        t2 = time.perf_counter()
+        print(f"[{mode}] prefill + {N_STEPS} steps {t2 - t1:.0f} s; own arg max tokens {toks}", flush=True)
+        if forced is None:
+            forced = list(toks)                                 # the emulated oracle's free-running greedy tokens
+            rec["tokens_emu"] = np.asarray(toks, np.int32)
+        rec[f"argmax_{mode}"] = np.asarray(toks, np.int32)      # (fp32: its own arg max at each teacher-forced step)
+        L = torch.stack(logits)                                 # [steps, vocab] fp32
+        top = torch.topk(L, N_TOP, dim=-1)
+        rec[f"top_ids_{mode}"] = top.indices.numpy().astype(np.int32)
+        rec[f"top_vals_{mode}"] = top.values.numpy().astype(np.float32)
+        rec[f"probe_{mode}"] = L[:, torch.from_numpy(probe.astype(np.int64))].numpy().astype(np.float32)
+        rec[f"range_{mode}"] = torch.stack([L.min(-1).values, L.max(-1).values], -1).numpy().astype(np.float32)
+        if mode == "emu":
+            rec["margins_emu"] = (top.values[:, 0] - top.values[:, 1]).numpy().astype(np.float32)
+        secs += [t1 - t0, t2 - t1]
+        rec["seconds"] = np.asarray(secs, np.float32)           # [tower_emu, lm_emu, tower_f32, lm_f32]
+        rec["threads"] = np.asarray([threads], np.int32)
+        OUT.parent.mkdir(exist_ok=True)
+        np.savez_compressed(OUT, **rec)                         # (partial file after the first mode: an interrupted run still leaves the emulated half)
+    print(f"wrote {OUT} ({OUT.stat().st_size / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()
