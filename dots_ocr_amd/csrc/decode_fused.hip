@@ -486,7 +486,9 @@ __global__ __launch_bounds__(1024) void dec_proj_wide_kernel(const bf16_t* __res
 }
 
 // grid.y = ceil(n_out / NM) workgroups, n_out = (Hq + 2 Hkv) * 8 whole 16-row tiles of the (permuted, launch_pack_frag_qkv) qkv weight.
-template <int NM, int TT, int NC, typename WT>
+// XIMG (round 6, batches above 32 rows): h is the NORMALISED X image of the rows (dec_norm_ximg_kernel, decode_b64.hip: the same row_rstd / norm8,
+// so the same bits) — no statistics, no in-register normalisation, no first barrier: a wave's fragments of its K slice are requested with its weights.
+template <int NM, int TT, int NC, typename WT, bool XIMG = false>
 __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w,
                                                             const WT* __restrict__ Wd, const float* __restrict__ wscale, const bf16_t* __restrict__ bias,
                                                             const float* __restrict__ inv_freq, const int32_t* __restrict__ ctx_len,
@@ -504,16 +506,28 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
     TRACE(0);
     // ---- 1. one round trip: the rows whose statistic this wave computes (wv, wv + 16, ...), its weight slice, the norm weights of its K
     // slice, the epilogue waves' small operands
-    u32x4 v[TT][NC];
+    u32x4 v[XIMG ? 1 : TT][XIMG ? 1 : NC];
+    u32x4 wf[XIMG ? 1 : NC];
+    bf16x8 xf[TT][NC];
+    if constexpr (XIMG) {
+        // lane (g, m) of k-step ks of tile t: 16 B at t * 32 H + ks * 1024 + lane * 16 (tiles past the batch re-read the last one)
+        const char* xb = reinterpret_cast<const char*>(h) + lane * 16;
+        const int n_bt = (B + 15) >> 4;
 #pragma unroll
-    for (int i = 0; i < TT; ++i) {
-        const int r = min(wv + 16 * i, B - 1);
+        for (int t = 0; t < TT; ++t)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[i][c] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + min(c * 512 + lane * 8, H - 8));
+            for (int o = 0; o < NC; ++o)
+                xf[t][o] = *reinterpret_cast<const bf16x8*>(xb + (size_t)min(t, n_bt - 1) * 32 * H + (size_t)min(k0 + o, KS - 1) * 1024);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const int r = min(wv + 16 * i, B - 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[i][c] = *reinterpret_cast<const u32x4*>(h + (size_t)r * H + min(c * 512 + lane * 8, H - 8));
+        }
+#pragma unroll
+        for (int o = 0; o < NC; ++o) wf[o] = *reinterpret_cast<const u32x4*>(ln_w + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
     }
-    u32x4 wf[NC];
-#pragma unroll
-    for (int o = 0; o < NC; ++o) wf[o] = *reinterpret_cast<const u32x4*>(ln_w + (size_t)min(k0 + o, KS - 1) * 32 + g * 8);
     const int e = 15 - wv;
     const bool ew = e < NM * TT;                                                  // wave-uniform
     const int je = ew ? e / TT : 0, te = ew ? e % TT : 0;
@@ -544,6 +558,15 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
     __builtin_amdgcn_sched_barrier(0);
     const int page = block_table[(size_t)mc * max_pages + (pos >> 6)];           // second (dependent) round trip, behind the weights
     __builtin_amdgcn_sched_barrier(0);
+    float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
+    if constexpr (XIMG) {
+        TRACE(1);
+        if (ew && rot) {                  // precise sincosf, as in dec_qkv_kernel (beside the other waves' loads)
+            sincosf((float)pos * fr0, &rs[0], &rc[0]);
+            sincosf((float)pos * fr1, &rs[1], &rc[1]);
+        }
+        TRACE(3);
+    } else {
     // ---- 2. statistics
 #pragma unroll
     for (int i = 0; i < TT; ++i)
@@ -560,7 +583,6 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
             if (lane == 0) rstd_s[r] = rstd;
         }
     }
-    float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
     if (ew && rot) {                  // precise sincosf, as in dec_qkv_kernel
         sincosf((float)pos * fr0, &rs[0], &rc[0]);
         sincosf((float)pos * fr1, &rs[1], &rc[1]);
@@ -570,7 +592,6 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
     // ---- 3. this wave's K slice of every row, normalised in registers: lane (g, m) of k-step ks holds X[16 t + m][32 ks + 8 g .. + 7].
     // (Requesting the raw fragments BEFORE the barrier — their addresses do not need the statistics — measured slower: 16.9 vs 15.7 us
     // on the partition, 16.3 vs 14.3 on the whole chip, profiles/r05_decode_wide_second_pass.txt.)
-    bf16x8 xf[TT][NC];
     {
         u32x4 raw[TT][NC];
         float rsd[TT];
@@ -587,6 +608,7 @@ __global__ __launch_bounds__(1024) void dec_qkv_wide_kernel(const bf16_t* __rest
             for (int o = 0; o < NC; ++o) xf[t][o] = __builtin_bit_cast(bf16x8, norm8(raw[t][o], wf[o], rsd[t]));
     }
     TRACE(3);
+    }
     // ---- 4. contraction: even k-steps, then odd k-steps (mfma_lds: acc0 / acc1)
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -961,11 +983,15 @@ static bool wide_on() {
 // (half as many workgroups) at B <= 16, as many features per workgroup as one round on those CUs needs above.
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
-                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus) {
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus, bf16_t* xn) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int full_tiles = part_cus > 0;
     if (B > 16 && wide_on()) {
-        static uint32_t attr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        static uint32_t attr_w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // round 6, above 32 rows: the rows are normalised once by a small kernel (X image in xn) instead of by every workgroup
+        static const bool ximg_on = !(getenv("DOTS_OCR_QKV_XIMG") && atoi(getenv("DOTS_OCR_QKV_XIMG")) == 0);     // A/B switch
+        const bool ximg = xn && B > 32 && ximg_on;
+        if (ximg) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps));
         const int n_out = (Hq + 2 * Hkv) * 8, cus = wide_cus(part_cus);
         const int nm = (n_out + cus - 1) / cus >= 2 ? 2 : 1, tt = B <= 32 ? 2 : 4;
         const size_t lds_w = (size_t)16 * nm * tt * 64 * sizeof(f32x4) + MAX_DECODE_ROWS * sizeof(float);
@@ -979,6 +1005,17 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
 #define QKV_WIDE(NMV, TTV, IDX)                                                                                                     \
         return wscale ? go(dec_qkv_wide_kernel<NMV, TTV, NC_MAX, u32x2>, (const u32x2*)Wd, &attr_w[IDX])                              \
                       : go(dec_qkv_wide_kernel<NMV, TTV, NC_MAX, bf16x8>, (const bf16x8*)Wd, &attr_w[IDX + 1])
+        if (ximg) {          // tt == 4
+            const bf16_t* hx = xn;
+            auto gox = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+                hipError_t e = ensure_lds(kern, lds_w, done);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, grid_w, dim3(1024), lds_w, s, hx, ln_w, wd, wscale, bias, inv_freq, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps);
+                return hipGetLastError();
+            };
+            if (nm == 1) return wscale ? gox(dec_qkv_wide_kernel<1, 4, NC_MAX, u32x2, true>, (const u32x2*)Wd, &attr_w[8]) : gox(dec_qkv_wide_kernel<1, 4, NC_MAX, bf16x8, true>, (const bf16x8*)Wd, &attr_w[9]);
+            return wscale ? gox(dec_qkv_wide_kernel<2, 4, NC_MAX, u32x2, true>, (const u32x2*)Wd, &attr_w[10]) : gox(dec_qkv_wide_kernel<2, 4, NC_MAX, bf16x8, true>, (const bf16x8*)Wd, &attr_w[11]);
+        }
         if (nm == 1 && tt == 2) { QKV_WIDE(1, 2, 0); }
         if (nm == 1) { QKV_WIDE(1, 4, 2); }
         if (tt == 2) { QKV_WIDE(2, 2, 4); }

@@ -1072,7 +1072,7 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_dec_qkv(s, e->d_h, L.ln1, L.qkv_wd, L.qkv_s, L.qkv_b, e->lm_inv_freq, e->ctx_len, e->block_table, e->max_pages, pool_l, e->d_q, B, H, Hq,
-                          Hkv, c.rms_norm_eps, part ? e->dec_cus : 0));
+                          Hkv, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale, part ? e->dec_cus : 0, e->attn_stream));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
         CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part ? e->dec_cus : 0));
@@ -1960,7 +1960,7 @@ int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* 
     CK(hipMemcpyAsync(freq, f, sizeof(f), hipMemcpyHostToDevice, e->stream));
     RET(op_weight(e, sc, (const bf16_t*)wqkv, (int64_t)(Hq + 2 * Hkv) * 128, H, Hq, Hkv, true, fp8, &wd, &wscale));
     CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
-                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps, e->force_part ? e->dec_cus : 0));      // dots_set_decode_plan(1): the partition plan's kernels
+                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps, e->force_part ? e->dec_cus : 0, e->d_xn));      // dots_set_decode_plan(1): the partition plan's kernels
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

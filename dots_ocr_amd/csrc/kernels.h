@@ -61,7 +61,7 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
 // (launch_pack_frag_fp8) and wscale[row] its fp32 per-output-channel scales (quant.hip).
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
-                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus = 0);
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus = 0, bf16_t* xn = nullptr);
 hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus = 0);   // h += X @ W^T
 // part_cus > 0 (all dense launchers): the stream is CU-masked to that many CUs.  qkv / proj: whole 16-row weight tiles per workgroup at B <= 16,
 // one round of wide workgroups above; gate|up: the grid is capped at what the CUs hold at once, the workgroups walk the (gate, up) tile pairs

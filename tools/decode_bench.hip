@@ -137,11 +137,11 @@ int main(int argc, char** argv) {
     const int full = getenv("DOTS_BENCH_FULL") ? 1 : 0;      // whole-tile projections (the half-chip launch plan)
     const int part_cus = full ? (getenv("DOTS_BENCH_CUS") ? atoi(getenv("DOTS_BENCH_CUS")) : 128) : 0;      // the partition plan caps gate|up's grid at what the partition holds
     printf("decode attention: %s\n", decode_attn_stream_wgs(B, Hkv, n_splits, max_pages, part_cus) ? "streaming kernel (one resident workgroup per CU)" : "one workgroup per (row, kv head, split)");
-    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, part_cus)); };
+    bf16_t* xn = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<bf16_t>((size_t)64 * H);      // scratch of the round-6 four-tile kernels (decode_b64.hip)
+    auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, part_cus, xn)); };
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale, part_cus)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
     auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, part_cus)); };
-    bf16_t* xn = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<bf16_t>((size_t)64 * H);      // scratch of the round-6 four-tile kernels (decode_b64.hip)
     auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus, xn)); };
     auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I, part_cus)); };
     auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps, part_cus, xn)); };
