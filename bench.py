@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--time-sliced", action="store_true",
                     help="the multi-batch pipeline WITHOUT CU partitions: per step the tower of the new batch, its prefill and the decode steps over all "
                          "rows in flight run one after the other, each on the whole chip (A/B against the partitioned default)")
+    ap.add_argument("--page-queue", action="store_true",
+                    help="mixed64: the ranks PULL pages from one shared queue (dp.PageQueue: a counter on the process group's host-side store, costliest pages "
+                         "first) as their slots drain, instead of the static cost shard — for jobs much larger than the ranks' slots, where a static shard "
+                         "leaves the ranks that drew short outputs idle at the end (SURVEY §8(e)).  Every rank keeps all pages' pixels resident.")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -230,8 +234,9 @@ def main():
     # ---- this rank's pages
     if mixed:
         sizes_all = mixed_pages(64)
-        shards = dp.shard_pages([dp.page_cost(patches_of(sz), a.max_new_tokens) for sz in sizes_all], world)
-        my_pages = shards[rank]
+        costs_all = [dp.page_cost(patches_of(sz), a.max_new_tokens) for sz in sizes_all]
+        shards = dp.shard_pages(costs_all, world)
+        my_pages = list(range(len(sizes_all))) if a.page_queue else shards[rank]      # --page-queue: any page may come to this rank, all are kept resident
         n_job_pages = len(sizes_all)
     else:
         size = {"tiny": (420, 588), "a4": A4_200DPI, "highres": HIGH_RES, "svg": SVG_CHART}[a.workload]
@@ -291,12 +296,60 @@ def main():
             off += n
         return grids
 
+    dyn = {"job": 0, "pages": None}
+
+    def step_page_queue(t0):
+        """mixed64 with --page-queue: this rank pulls page indices from the job's shared queue as its slots drain; a pulled page is tokenised and
+        preprocessed (GPU) then, so per job every page is still preprocessed, encoded, prefilled and decoded exactly once over all ranks."""
+        from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+        pq = dp.PageQueue(costs_all, store=dp.PageQueue.default_store(), key="dots_ocr/page_queue/%d" % dyn["job"], world_size=world)
+        dyn["job"] += 1
+        offs = np.concatenate([[0], np.cumsum(n_patches)])
+        t_host = [0.0, 0.0]
+
+        def pull(k):
+            got = []
+            for p_ in pq.take(k):
+                ta = time.perf_counter()
+                pr = tokenize(n_patches[p_] // 4, p_)
+                tb = time.perf_counter()
+                g = eng.preprocess_image(page_dev[p_], pix_dev + int(offs[p_]) * v.patch_dim * 4, shape=page_arrays[p_].shape[:2])
+                t_host[0] += tb - ta; t_host[1] += time.perf_counter() - tb
+                got.append((p_, Request(pr, pix[int(offs[p_]):int(offs[p_ + 1])], np.asarray([g], np.int64), a.max_new_tokens)))
+            return got
+        ag = os.environ.get("DOTS_BENCH_ADMIT_GROUP")
+        cb = ContinuousBatcher(eng, eos_ids=(), prefetch=int(os.environ.get("DOTS_BENCH_PREFETCH", str(slots))), admit_group=int(ag) if ag else None)
+        reqs_by_page = {}
+
+        def pull_keep(k):
+            got = pull(k)
+            reqs_by_page.update(got)
+            return got
+        done = cb.run_pull(pull_keep)
+        mine = sorted(done)
+        dyn["pages"] = mine
+        mixed_meter["decode_steps"] += cb.decode_steps
+        mixed_meter["requests"].append([(len(reqs_by_page[p_].input_ids), len(done[p_])) for p_ in mine])
+        mixed_meter["last_reqs"], mixed_meter["last_outs"] = [reqs_by_page[p_] for p_ in mine], [done[p_] for p_ in mine]
+        out = np.zeros((len(mine), a.max_new_tokens), np.int32)
+        out_lens = np.zeros(len(mine), np.int32)
+        for i, p_ in enumerate(mine):
+            out[i, :len(done[p_])], out_lens[i] = done[p_], len(done[p_])
+        t3 = time.perf_counter()
+        texts = proc.batch_decode([out[i, :out_lens[i]] for i in range(len(out_lens))])
+        host_ms["tokenize_ms"] += t_host[0] * 1e3
+        host_ms["preprocess_ms"] += t_host[1] * 1e3
+        host_ms["detokenize_ms"] += (time.perf_counter() - t3) * 1e3
+        return out, out_lens, texts, [reqs_by_page[p_].input_ids for p_ in mine]
+
     def step(pipelined=False):
         """One batch: tokenise, GPU preprocessing, tower, prefill, greedy decode, detokenise.  pipelined: the tower rows of THIS batch were
         prefetched during the previous step and are taken now; the preprocessing + tower launched here are those of the NEXT batch and
         run on the CU-masked side stream while this batch's decode loop runs on the other CU partition.  Per step the same work either
         way: one preprocessing pass, one tower, one prefill, one decode loop."""
         t0 = time.perf_counter()
+        if mixed and a.page_queue:
+            return step_page_queue(t0)
         prompts = [tokenize(n // 4, pn) for n, pn in zip(n_patches, my_pages)]
         t1 = time.perf_counter()
         if pipelined:
@@ -503,6 +556,9 @@ def main():
     # the only data-path collective of the job — the gather of the generated token ids on rank 0 (dp.py: two all_gathers over RCCL) —
     # is INSIDE the timed region, timed on its own as well
     tg = time.perf_counter()
+    if mixed and a.page_queue:                       # the pages this rank drew in the last job (any subset of the job; the gather restores page order)
+        my_pages = dyn["pages"]
+        sizes = [sizes_all[p_] for p_ in my_pages]
     gathered = dp.gather_token_ids(out, out_lens, page_index=my_pages)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
@@ -611,6 +667,10 @@ def main():
                                          f"max_new_tokens={a.max_new_tokens}, EOS disabled",
                              "pages_per_gpu": [len(s) for s in shards], "slots_per_gpu": slots,
                              "occupied_slots_per_gpu_at_start": [min(slots, len(s)) for s in shards], "parallelism": f"dp{world}"}
+            if a.page_queue:
+                res["config"]["page_queue"] = ("--page-queue: NOT the static shard described above — the ranks pulled page indices from one shared queue (dp.PageQueue, "
+                                               "costliest first, a fetch-and-add on the process group's host-side store) as their slots drained; "
+                                               f"rank 0 drew {len(my_pages)} pages in the last job")
             occ = max(min(slots, len(s)) for s in shards)
             res["scaling_note"] = (
                 f"strong scaling of a FIXED 64-page job: a rank holding {max(len(s) for s in shards)} pages decodes at most {occ} sequences at a time, and decode "

@@ -574,9 +574,16 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
     if (const char* fm = getenv("DOTS_OCR_DECODE_PLAN")) {
+        // the same rule as dots_set_decode_plan: a bit field since round 5 (bit 0 partition plan, + 2 streaming / + 4 per-split attention) — it used to be
+        // "any non-zero = partition plan", so an old setting of 2 or 3 now means the (slower) streaming attention kernel: values outside 0..5 and 6 / 7
+        // (both attention bits) are refused instead of silently re-interpreted
         const int plan = atoi(fm);
-        e->force_part = plan & 1;
-        e->attn_stream = (plan & 2) ? 1 : (plan & 4) ? 0 : -1;
+        if (plan < 0 || plan > 5 || (plan & 6) == 6) {
+            fprintf(stderr, "dots.ocr: DOTS_OCR_DECODE_PLAN=%s ignored: must be 0 / 1 (partition plan on every step), + 2 (streaming attention) or + 4 (per-split attention)\n", fm);
+        } else {
+            e->force_part = plan & 1;
+            e->attn_stream = (plan & 2) ? 1 : (plan & 4) ? 0 : -1;
+        }
     }
     if (const char* v = getenv("DOTS_OCR_TOWER_TAIL_LAYERS")) e->tail_fixed = std::max(-1, std::min(atoi(v), c.v_layers));      // dots_tower_tail
     // every slot starts free: its block-table row points at the scratch page (an idle row of the fixed-shape decode graph
@@ -898,6 +905,13 @@ int launch_prefetched_tower(DotsEngine* e) {
     e->vs = e->s_vit;
     int r = vit_forward(e, e->pref_pix, e->pref_patches, e->pref_grid.data(), (int)(e->pref_grid.size() / 3), nullptr, e->vis_pref, &e->vis_pref_rows);
     e->vs = e->stream;
+    // a tower that failed AFTER switching to the unmasked tail stream returned without chaining it back: whatever it queued on
+    // s_vit_full must still be covered by the event below, which the next tower / dots_vit_forward wait on before reusing v_x / v_qkv.
+    // (After a complete tower this is one more event pair on already-ordered streams.)
+    if (e->s_vit_full) {
+        const int rc = chain_streams(e, e->s_vit_full, e->s_vit);
+        if (r == DOTS_OK) r = rc;
+    }
     CK(hipEventRecord(e->ev_vis_ready, e->s_vit));
     if (r != DOTS_OK) e->pref_pending = false;           // nothing to take
     return r;

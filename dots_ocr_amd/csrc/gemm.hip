@@ -39,7 +39,9 @@ DEVI float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.707106781186
 // v_div_fmas, v_div_fixup); 128 of them per lane made the SwiGLU epilogue of the one-wave-per-SIMD kernel 17 k cycles per tile against
 // 9 k for a plain one (profiles/r05_gemm_w4_cycle_stamps.txt).  Here: reciprocal + ONE Newton correction of the quotient (error < 1 ulp
 // of fp32 before the single rounding to bf16; the exponent is clamped so that 1 + e^-x stays finite and 0 * inf cannot appear).
-// -DGEMM_EXACT_SILU restores the division.
+// -DGEMM_EXACT_SILU restores the division.  BOTH GEMM plans and the fp8 twin share this function, so "bit-identical" holds between plans, not
+// against builds before round 5: an output may differ from the exact quotient's bf16 rounding by one bf16 ulp, and for x < -88 the result is a
+// tiny negative instead of -0 (tests/test_kernels_gpu.py: test_gemm_swiglu_epilogue_is_within_one_bf16_ulp_of_the_exact_quotient).
 #ifdef GEMM_EXACT_SILU
 DEVI float silu(float x) { return x / (1.0f + __expf(-x)); }
 #else

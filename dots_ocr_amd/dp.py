@@ -8,7 +8,7 @@ collective anywhere on the data path except ONE gather of the generated token id
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
@@ -35,6 +35,44 @@ def shard_pages(costs: Sequence[float], world_size: int) -> List[List[int]]:
         bins[r].append(i)
         load[r] += costs[i]
     return [sorted(b) for b in bins]
+
+
+class PageQueue:
+    """Shared work queue over the pages of ONE job, for jobs much larger than the ranks' slots (SURVEY §8(e) "scaling risks": with a
+    static shard the ranks that drew long outputs finish last while the others idle).  The job's pages are put in ONE order known to
+    every rank (costliest first: big pages start early, small ones fill the tail); a rank takes the next page(s) whenever its slots
+    drain.  The only shared state is one integer, fetched-and-added on the process group's HOST-side key-value store (the TCPStore
+    torch.distributed already runs for the rendezvous): no GPU collective, nothing on the data path — the result gather stays the
+    job's only collective.  Single process (no store): a local counter, i.e. the same order served to one rank.
+    Opt-in (bench.py --page-queue, ContinuousBatcher.run_pull); the default stays the static LPT shard of shard_pages."""
+
+    def __init__(self, costs: Sequence[float], store=None, key: str = "dots_ocr/page_queue", world_size: int = 1):
+        self.order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+        self.store, self.key, self._local = store, key, 0
+        # one call hands out at most half a rank's fair share: a rank with many free slots (32 per GPU in bench.py's mixed64) fills them over
+        # several scheduler steps instead of emptying the queue before the other ranks have asked
+        self.max_take = max(1, len(self.order) // (2 * max(1, int(world_size))))
+
+    @staticmethod
+    def default_store():
+        """the initialised default process group's store, or None (single process)"""
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from torch.distributed import distributed_c10d as c10d
+                return c10d._get_default_store()
+        except Exception:
+            pass
+        return None
+
+    def take(self, n: int = 1) -> List[int]:
+        """the next n page indices of the job (fewer, or none, at the end); each index is handed out exactly once over all ranks"""
+        n = max(1, min(int(n), self.max_take))
+        if self.store is None:
+            start, self._local = self._local, self._local + n
+        else:
+            start = int(self.store.add(self.key, n)) - n             # atomic fetch-and-add on the store's server
+        return self.order[start:start + n] if start < len(self.order) else []
 
 
 def gather_token_ids(out_ids: np.ndarray, out_lens: np.ndarray, page_index: Sequence[int] | None = None):

@@ -345,8 +345,10 @@ class Engine:
         self._ck(self.lib.dots_set_gemm_plan(self.h, int(plan)), "dots_set_gemm_plan")
 
     def tower_tail(self, set: int = -2) -> int:
-        """Blocks of a prefetched tower that run on the whole chip instead of the tower's CU partition: set = -1 adaptive (default: sized
-        from the previous launch's events so that the partition part ends with the decode loop), >= 0 fixed (0 = off), -2 = query only.
+        """Blocks of a prefetched tower that run on the whole chip instead of the tower's CU partition: set >= 0 fixed (0 = off, the engine's
+        DEFAULT), -1 adaptive (opt-in: sized from the previous launch's events so that the partition part ends with the decode loop — the rule
+        reads "the host stopped issuing decode chunks" as "the decode loop drained", which holds for bench.py's closed a4 pipeline and NOT for a
+        serving loop that keeps slots occupied: do not copy it into one), -2 = query only (this method's default argument).
         Returns the tail of the tower launched last."""
         now = C.c_int32(0)
         self._ck(self.lib.dots_tower_tail(self.h, int(set), C.byref(now)), "dots_tower_tail")

@@ -175,6 +175,8 @@ class ContinuousBatcher:
         self.engine.slots_prefill(slots, np.concatenate([r.input_ids for _, _, r in group]), lens, caps)
         for s, rid, r in group:
             self.running[s] = (rid, r)
+            self._last_lens[s] = 0                   # a reused slot must not inherit its previous occupant's length (_soon_free counted a
+                                                     # just-admitted long request as "about to finish" and the look-ahead group was sized for slots that stayed busy)
         self.admissions += 1
 
     def _admit(self, group):
@@ -265,7 +267,6 @@ class ContinuousBatcher:
     # ------------------------------------------------------------------ main loop
     def _collect(self) -> List[Tuple[int, Request, np.ndarray]]:
         fin, lens = self.engine.slots_poll()
-        self._last_lens = {s: int(lens[s]) for s in self.running}
         done = []
         for s in sorted(self.running):
             if fin[s] == 1:
@@ -280,6 +281,7 @@ class ContinuousBatcher:
                     self.kv_truncated += int(req.kv_truncated)
                 done.append((rid, req, toks))
                 self.engine.slot_release(s)
+        self._last_lens = {s: int(lens[s]) for s in self.running}      # after the finished slots have left: only what is still decoding
         return done
 
     def step(self) -> List[Tuple[int, Request, np.ndarray]]:
@@ -316,6 +318,29 @@ class ContinuousBatcher:
         self.engine.slots_decode(self.chunk)
         self.decode_steps += self.chunk
         return self._collect()
+
+    def run_pull(self, pull, low_water: Optional[int] = None) -> Dict[object, np.ndarray]:
+        """An open-ended job: `pull(k)` returns up to k (key, Request) pairs from a source shared with other ranks ([] = the source is dry;
+        dots_ocr_amd.dp.PageQueue).  Requests are pulled only as they can be used — while fewer than `low_water` (default: the look-ahead
+        group size, at least one) are queued beyond what the free slots can take — so a rank never hoards pages another rank could start.
+        Returns {key: new token ids}."""
+        low = max(1, self.prefetch) if low_water is None else max(1, int(low_water))
+        keys: Dict[int, object] = {}
+        out: Dict[object, np.ndarray] = {}
+        dry = False
+        while True:
+            want = low + len(self.free_slots()) - len(self._ahead) - len(self.pending)       # what the free slots can take now + the look-ahead's next group
+            if not dry and want > 0:
+                got = pull(want)
+                dry = not got
+                for key, req in got:
+                    keys[self.submit(req)] = key
+            if self.idle:
+                if dry:
+                    return out
+                continue
+            for rid, _, toks in self.step():
+                out[keys.pop(rid)] = toks
 
     def run(self, requests: Iterable[Request]) -> List[np.ndarray]:
         ids = [self.submit(r) for r in requests]

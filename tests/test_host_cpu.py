@@ -400,6 +400,113 @@ def test_data_parallel_job_equals_single_rank_world_size_2_gloo():
     assert got[0] == want and got[1] == want
 
 
+# ---- round 6: the mixed64 job of bench.py at world_size 8 (gloo, stand-in slot engine), static LPT shard and shared page queue
+def _mixed64_job():
+    """bench.py's configs[3] page mix (seed 2025): (first prompt token, prompt tokens, patches, cap, cost) per page.  Caps vary (seeded) so that the
+    ranks' shards do not finish together — the case the shared queue exists for."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from dots_ocr_amd import dp as _dp
+    from dots_ocr_amd.image_utils import smart_resize
+    cfg = DotsConfig()
+    rng = np.random.default_rng(64)
+    job = []
+    for i, (w, h) in enumerate(bench.mixed_pages(64)):
+        rh, rw = smart_resize(h, w, 28, cfg.min_pixels, cfg.max_pixels)
+        n = (rh // 14) * (rw // 14)
+        cap = int(rng.integers(8, 48))
+        job.append((100 + i, 12 + i % 7, n, cap, _dp.page_cost(n, 1024)))
+    return job
+
+
+def _mixed64_requests(page_ids):
+    from dots_ocr_amd.scheduler import Request
+    job = _mixed64_job()
+    return [Request(np.full(job[p][1], job[p][0], np.int32), np.zeros((job[p][2], 1), np.float32), np.array([[1, job[p][2] // 4, 4]]), job[p][3]) for p in page_ids]
+
+
+def _mixed64_engine():
+    sys.path.insert(0, str(ROOT / "tests"))
+    from fakes import FakeSlotEngine
+    return FakeSlotEngine(lambda prompt: int(prompt[0]) * 1000 + np.arange(64), max_batch=8, max_patches=8 * 35000, max_prefill_tokens=512, max_seq_len=256)
+
+
+def _pad(outs):
+    ids = np.zeros((len(outs), 64), np.int32)
+    lens = np.zeros((len(outs),), np.int32)
+    for j, o in enumerate(outs):
+        ids[j, :len(o)], lens[j] = o, len(o)
+    return ids, lens
+
+
+def _mixed64_worker(rank, world, port, q, queue_mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dots_ocr_amd import dp as _dp
+    from dots_ocr_amd.scheduler import ContinuousBatcher
+    from test_host_cpu import _mixed64_engine, _mixed64_job, _mixed64_requests, _pad
+    costs = [c for (_, _, _, _, c) in _mixed64_job()]
+    cb = ContinuousBatcher(_mixed64_engine(), chunk=4, prefetch=2)
+    if queue_mode:
+        pq = _dp.PageQueue(costs, store=_dp.PageQueue.default_store(), world_size=world)
+        assert pq.store is not None and pq.max_take == 4
+        done = cb.run_pull(lambda k: [(p, r) for p, r in zip(*(lambda ps: (ps, _mixed64_requests(ps)))(pq.take(k)))])
+        mine = sorted(done)
+        ids, lens = _pad([done[p] for p in mine])
+    else:
+        mine = _dp.shard_pages(costs, world)[rank]
+        ids, lens = _pad(cb.run(_mixed64_requests(mine)))
+    q.put((rank, mine, _dp.gather_token_ids(ids, lens, page_index=mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("queue_mode", [False, True])
+def test_mixed64_job_over_8_ranks_equals_one_rank_gloo(queue_mode):
+    """bench.py's mixed64 sharding path at the world size the driver's scaling run uses.  8 gloo ranks, the configs[3] page
+    mix, a stand-in slot engine per rank: (a) the static cost shard — LPT max / mean load <= 1.05 on the seed-2025 mix — and (b) the shared page
+    queue (dp.PageQueue over the process group's store: every page handed out exactly once, ranks pull as their slots drain); either way every
+    rank ends with the whole job in page order, equal to the single-rank run."""
+    import torch.multiprocessing as mp
+    from dots_ocr_amd import dp as _dp
+    from dots_ocr_amd.scheduler import ContinuousBatcher
+    job = _mixed64_job()
+    costs = [c for (_, _, _, _, c) in job]
+    shards = _dp.shard_pages(costs, 8)
+    loads = [sum(costs[i] for i in sh) for sh in shards]
+    assert sorted(i for sh in shards for i in sh) == list(range(64))
+    assert max(loads) / (sum(loads) / 8) <= 1.05, loads
+    outs = ContinuousBatcher(_mixed64_engine(), chunk=4, prefetch=2).run(_mixed64_requests(range(64)))
+    want = [(p, o.tolist()) for p, o in enumerate(outs)]
+    assert all(len(t) == job[p][3] and t[0] == job[p][0] * 1000 for p, t in want)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (7 if queue_mode else 0)
+    procs = [ctx.Process(target=_mixed64_worker, args=(r, 8, port, q, queue_mode)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    taken = sorted(i for _, mine, _ in got for i in mine)
+    assert taken == list(range(64)), "every page exactly once over the ranks"
+    for _, _, gathered in got:
+        assert gathered == want
+    # (which rank drew which page depends on the ranks' timing — here the stand-in engines are instant — and must not matter)
+
+
+def test_page_queue_single_process_serves_the_cost_order_once():
+    from dots_ocr_amd import dp as _dp
+    pq = _dp.PageQueue([1.0, 5.0, 3.0, 5.0, 0.5])
+    assert pq.take(2) == [1, 3] and pq.take(1) == [2] and pq.take(4) == [0, 4] and pq.take(3) == [] and pq.take() == []
+    pq = _dp.PageQueue(list(range(64)), world_size=8)                 # one call: at most half a rank's fair share
+    assert pq.max_take == 4 and pq.take(34) == [63, 62, 61, 60] and pq.take(1) == [59]
+
+
 def test_markdown_post_processing_matches_reference_goldens():
     """get_formula_in_markdown / clean_text / layoutjson2md / fix_streamlit_formulas == the reference functions
     (dots_ocr/utils/format_transformer.py) on every case of tests/golden/format_transformer.json."""
@@ -872,6 +979,32 @@ def test_scheduler_look_ahead_group_is_capped_by_the_slots_that_are_or_will_soon
     while not cb2.idle:
         outs += cb2.step()
     assert sorted(r.tag for _, r, _ in outs) == list(range(1, 9)) and all(len(t) == 150 for _, _, t in outs)
+
+
+def test_scheduler_reused_slot_does_not_inherit_the_previous_occupants_length():
+    """`_last_lens` kept a finished sequence's final length, so a request admitted into that slot looked "about to finish" to the
+    look-ahead that runs right after the admission: the prefetched group was sized for slots that stayed busy and, being all-or-nothing
+    (nothing may overtake it), held freed slots idle.  Wave 1 (four requests that run to 1000 tokens) leaves stale lengths of 1000 behind;
+    wave 2 has caps 250 / 250 / 250 / 1000; with the stale lengths wave 3 was prefetched as ONE group of four and waited for the 1000-token
+    sequence while three slots idled for 750 steps."""
+    from fakes import FakeSlotEngine
+    from dots_ocr_amd.scheduler import ContinuousBatcher, Request
+    mk = lambda i, cap: Request(np.full(8, i, np.int32), np.zeros((16, 4), np.float32), np.asarray([[1, 4, 4]]), cap, tag=i)
+    eng = FakeSlotEngine(lambda prompt: int(prompt[0]) + np.arange(4096), max_batch=4, max_patches=100, max_prefill_tokens=64, max_seq_len=8192)
+    cb = ContinuousBatcher(eng, chunk=4, prefetch=4, tower_steps_per_page=1)
+    for i, cap in enumerate([1000] * 4 + [250, 250, 250, 1000] + [250] * 4, 1):
+        cb.submit(mk(i, cap))
+    outs, idle_while_waiting = [], 0
+    while not cb.idle:
+        outs += cb.step()
+        for s, (_, r) in cb.running.items():                   # a tracked length never exceeds what its CURRENT occupant may generate
+            assert cb._last_lens.get(s, 0) <= r.max_new_tokens
+        if cb.pending or cb._ahead:
+            idle_while_waiting += (4 - len(cb.running)) * cb.chunk
+    assert sorted(r.tag for _, r, _ in outs) == list(range(1, 13)) and all(len(t) == r.max_new_tokens for _, r, t in outs)
+    # wave 1 ends at 1000, wave 2's long request at 2000; wave 3 fits behind the three short ones (250 + 250 < 1000): ~2000 steps (2250 with the stale lengths)
+    assert cb.decode_steps <= 2000 + 16 * cb.chunk, cb.decode_steps
+    assert idle_while_waiting <= 16 * cb.chunk, idle_while_waiting
 
 
 def test_scheduler_cold_start_ramp_and_tower_readiness_gate():

@@ -144,6 +144,34 @@ def test_gemm_swiglu(eng, M, I, K):
     close(out, bf(ref))
 
 
+def test_gemm_swiglu_epilogue_is_within_one_bf16_ulp_of_the_exact_quotient(eng):
+    """the shared SwiGLU epilogue computes silu as rcp + one Newton step (gemm.hip: silu; -DGEMM_EXACT_SILU restores the IEEE
+    division).  With identity weight blocks the GEMM hands the epilogue EXACT gate / up values, so the epilogue alone is compared with the
+    exact x / (1 + e^-x) * u (fp64) over the whole range: at most one bf16 ulp apart, including x < -88 where e^-x overflows fp32 (the
+    fast form returns a tiny negative or -0, never NaN / inf)."""
+    from dots_ocr_amd import engine as E
+    I = 128
+    g = torch.Generator().manual_seed(77)
+    x = torch.cat([torch.linspace(-120, 30, 1024), torch.randn(1024, generator=g) * 4, torch.tensor([-100., -88.5, -87., -20., -1e-3, 0., 1e-3, 20., 60.])])
+    M = (x.numel() + I - 1) // I
+    x = bf(torch.cat([x, torch.zeros(M * I - x.numel())]).view(M, I))
+    u = bf(torch.randn(M, I, generator=g) * 2)
+    A = torch.cat([x, u], 1)                                         # [M, 2 I]
+    eye, zero = torch.eye(I), torch.zeros(I, I)
+    gate, up = bf(torch.cat([eye, zero], 1)), bf(torch.cat([zero, eye], 1))
+    out = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
+    run(eng, eng.op_gemm, dev(A).data_ptr(), dev(_pack_w13(gate, up)).data_ptr(), 0, 0, out.data_ptr(), M, 2 * I, 2 * I, E.EPI_SWIGLU)
+    got = out.float().cpu().double()
+    xd, ud = x.double(), u.double()
+    exact = xd / (1.0 + torch.exp(-xd)) * ud
+    ref = exact.float().to(torch.bfloat16).double()
+    assert torch.isfinite(got).all()
+    ulp = torch.maximum(ref.abs(), torch.full_like(ref, 2.0 ** -126)) * 2.0 ** -7          # one bf16 ulp at the reference's magnitude (upper bound)
+    bad = (got - ref).abs() > ulp
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} SwiGLU outputs differ from the exact quotient by more than one bf16 ulp; worst x = {float(xd[bad][0])}"
+    assert (got[xd < -88].abs() < 1e-30).all()
+
+
 def _vt_reference(v, lens):
     """v [T, H, 128] -> V^T [H, 128, Tpad] with the kernel's padding and 16-key group order."""
     H = v.shape[1]
