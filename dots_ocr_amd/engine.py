@@ -245,6 +245,11 @@ class Engine:
         self._ck(self.lib.dots_memcpy_h2d(self.h, C.c_void_p(p), a.ctypes.data_as(C.c_void_p), a.nbytes), "dots_memcpy_h2d")
         return p
 
+    def copy_to_device(self, ptr: int, a: np.ndarray):
+        """host array -> an existing device buffer (blocking)"""
+        a = np.ascontiguousarray(a)
+        self._ck(self.lib.dots_memcpy_h2d(self.h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes), "dots_memcpy_h2d")
+
     def to_host(self, ptr: int, shape: Sequence[int], dtype) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         self._ck(self.lib.dots_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes), "dots_memcpy_d2h")

@@ -160,7 +160,8 @@ def test_gemm_swiglu_epilogue_is_within_one_bf16_ulp_of_the_exact_quotient(eng):
     eye, zero = torch.eye(I), torch.zeros(I, I)
     gate, up = bf(torch.cat([eye, zero], 1)), bf(torch.cat([zero, eye], 1))
     out = torch.empty(M, I, dtype=torch.bfloat16, device="cuda")
-    run(eng, eng.op_gemm, dev(A).data_ptr(), dev(_pack_w13(gate, up)).data_ptr(), 0, 0, out.data_ptr(), M, 2 * I, 2 * I, E.EPI_SWIGLU)
+    Ad, Wd = dev(A), dev(_pack_w13(gate, up))                        # (named: a temporary's block may be handed to the next allocation)
+    run(eng, eng.op_gemm, Ad.data_ptr(), Wd.data_ptr(), 0, 0, out.data_ptr(), M, 2 * I, 2 * I, E.EPI_SWIGLU)
     got = out.float().cpu().double()
     xd, ud = x.double(), u.double()
     exact = xd / (1.0 + torch.exp(-xd)) * ud
