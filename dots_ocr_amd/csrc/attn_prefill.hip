@@ -390,6 +390,12 @@ constexpr int RING_BYTES = RING * 2 * KT_BYTES;               // KT_BYTES == VT_
 template <int... I, class F> DEVI void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEVI void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// CAUSAL (round 6: the LM prefill, until now on the 8-wave kernel of rounds 1-3): query row i sees keys 0 .. i of its sequence.  A workgroup's 256 query
+// rows need the KV tiles up to their own last row only (the tile count is cut, so the DMA never fetches past it), and a wave masks the tiles that
+// reach past ITS first row — per element, in the block that already masks a ragged last tile (keys above a row's own position become -inf before the
+// maxima see them; a tile wholly above a wave's rows costs that wave one masked tile: the four waves share the ring and its barriers).  Nothing else in
+// the schedule changes: same gaps, same fillers, same bits for the bidirectional instantiation.
+template <bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_attn64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
     bf16_t* __restrict__ O, const QBlock* __restrict__ blocks, int n_items, int64_t T, int64_t Tpad, int Hq, int group,
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
     const int h = qb.head, hkv = h / group, n = qb.n;
     const int tid = threadIdx.x, l = tid & 63, l31 = l & 31, hi = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tiles = (n + 63) >> 6;
+    const int n_tiles = CAUSAL ? min((n + 63) >> 6, (qb.q0 + 256 + 63) >> 6) : (n + 63) >> 6;      // causal: no key beyond the workgroup's last row
     const int t_last = n_tiles - 1;
 
     // ---- Q fragments of the two blocks: B operand, lane (q, hi) holds Q[q][16 ks + 8 hi .. +7]
@@ -494,16 +500,18 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
         const int kl = lds0 + k_lane + ((j + 1) & 3) * 2 * KT_BYTES, vl = lds0 + v_lane + ((j & 3) * 2 + 1) * KT_BYTES;
         // fa[0] = the first K fragments of this tile: read behind the previous tile's barrier
         const int key0 = j * 64;
-        if (key0 + 64 > n) {                                      // ragged last tile / the padding tile of an odd count (rare): keys past the end
-#pragma unroll                                                    // hold whatever the spare K rows held -> -inf before the maxima see them
-            for (int bk = 0; bk < 2; ++bk)
+        if (key0 + 64 > n || (CAUSAL && key0 + 63 > qb.q0 + w * 64)) {   // ragged last tile / the padding tile of an odd count (rare): keys past the end
+#pragma unroll                                                    // hold whatever the spare K rows held -> -inf before the maxima see them;
+            for (int bk = 0; bk < 2; ++bk) {                      // causal: the tiles on and above this wave's diagonal (wave-uniform condition)
+                const int qrow = qb.q0 + w * 64 + bk * 32 + l31;
 #pragma unroll
                 for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = key0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        sc[bk][tq][r] = key < n ? sc[bk][tq][r] : -INFINITY;
+                        sc[bk][tq][r] = (key < n && (!CAUSAL || key <= qrow)) ? sc[bk][tq][r] : -INFINITY;
                     }
+            }
         }
         // ---- gaps 0-5: score MFMAs || row maxima of S(j) (6 + 5 + 5 v_max3 per block); gaps 6-7: the decision chain
         float mx[2] = {-INFINITY, -INFINITY};
@@ -716,17 +724,20 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
         return hipGetLastError();
     };
     if (flash_rows_per_block() == 256) {
-        if (mode == 2 && !causal) {
+        // causal (LM prefill) on the 64-row kernel since round 6; DOTS_OCR_PREFILL_F64=0: the 8-wave kernel of rounds 1-3 (A/B switch)
+        static const bool causal64 = !(getenv("DOTS_OCR_PREFILL_F64") && atoi(getenv("DOTS_OCR_PREFILL_F64")) == 0);
+        if (mode == 2 && (!causal || causal64)) {
             // dynamic LDS > 64 KB is opted into once per DEVICE (engines on several GPUs may live in one process): bit d of the mask
-            static uint32_t attr_done = 0;
+            static uint32_t attr_done[2] = {0, 0};
             int dev = 0;
             hipError_t e = hipGetDevice(&dev);
             if (e != hipSuccess) return e;
             const uint32_t bit = 1u << (dev & 31);
-            if (!(__atomic_load_n(&attr_done, __ATOMIC_ACQUIRE) & bit)) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+            if (!(__atomic_load_n(&attr_done[causal ? 1 : 0], __ATOMIC_ACQUIRE) & bit)) {
+                e = causal ? hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
                 if (e != hipSuccess) return e;
-                __atomic_fetch_or(&attr_done, bit, __ATOMIC_RELEASE);
+                __atomic_fetch_or(&attr_done[causal ? 1 : 0], bit, __ATOMIC_RELEASE);
             }
             XcdPlan pl;
             if (plan) pl = *plan;
@@ -736,7 +747,8 @@ hipError_t launch_flash_attn(hipStream_t s, const bf16_t* q, const bf16_t* k, co
             }
             int mx = 0;
             for (int x = 0; x < 8; ++x) mx = std::max(mx, (int)pl.cnt[x]);
-            hipLaunchKernelGGL(flash_attn64_kernel, dim3(8 * mx), dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c, pl);
+            if (causal) hipLaunchKernelGGL(flash_attn64_kernel<true>, dim3(8 * mx), dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c, pl);
+            else hipLaunchKernelGGL(flash_attn64_kernel<false>, dim3(8 * mx), dim3(256), RING_BYTES, s, q, k, vt, out, blocks, n_blocks, T, Tpad, Hq, Hq / Hkv, c, pl);
             return hipGetLastError();
         }
         if (mode >= 1) return causal ? go(flash_attn_kernel<true, 8, 1>, 512, 3 * BUF_BYTES) : go(flash_attn_kernel<false, 8, 1>, 512, 3 * BUF_BYTES);

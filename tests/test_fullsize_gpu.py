@@ -163,7 +163,7 @@ def test_causal_gqa_full_prompt_length_sampled_rows(eng):
     # first row sees only key 0
     assert (out[0] - v[0].float().cpu().repeat_interleave(6, 0)).abs().max().item() < 0.02
     kf, vf = k.float().cpu().repeat_interleave(6, 1), v.float().cpu().repeat_interleave(6, 1)
-    for r in (1, 63, 64, 127, 128, 2600, T - 1):
+    for r in (1, 63, 64, 127, 128, 191, 192, 255, 256, 257, 2600, 4863, 4864, 5119, 5120, T - 1):      # every wave boundary of a 256-row block, first and last blocks
         ref = om._attention(q[r:r + 1].float().cpu().transpose(0, 1), kf[:r + 1].transpose(0, 1), vf[:r + 1].transpose(0, 1),
                             1 / math.sqrt(128), False, True).transpose(0, 1)[0]
         assert (out[r] - ref).abs().max().item() < 4e-3 + 2 ** -6 * ref.abs().max().item(), r
