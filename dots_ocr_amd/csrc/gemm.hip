@@ -615,7 +615,18 @@ DEVI void w4_epilogue_lds(const f32x16 (&acc)[4][4], const W4Cols& cc, bool has_
             }
         }
     };
-    const int wslot = (l31 & 15) << 1;
+    // Slot swizzle of the transposition image (a row = 32 slots of 16 B = TWO passes over the 64 banks, so slots s and s + 16 share banks).  Round 5's
+    // f(row) = (row & 15) << 1 left every ds_read_b128 two-way conflicted: the 16 lanes one LDS cycle serves come from two (SwiGLU: four) consecutive
+    // rows and asked for the same eight EVEN slot residues mod 16 in each (r05_pmc_gemm.json: 19 % of the LDS-active cycles were conflict cycles, all
+    // here).  Round 6: odd rows also flip slot bit 0, rows with bit 1 set flip slot bit 3 — the rows of a lane group now cover disjoint residues
+    // (even / odd, low / high) on the read side, and the eight rows of a ds_write_b128 lane group still hit eight distinct residues.  Same values
+    // to the same addresses of C: bit-identical results.  -DW4_OLD_SWZ restores the round-5 swizzle (A/B).
+#ifdef W4_OLD_SWZ
+    auto swz = [](int row) { return (row & 15) << 1; };
+#else
+    auto swz = [](int row) { return ((row & 15) << 1) ^ (row & 1) ^ ((row & 2) << 2); };
+#endif
+    const int wslot = swz(l31);
     char* const wrow = stage2 + l31 * 512;
 #define W4_PUT(FM, IMG)                                                                                                   \
     _Pragma("unroll") for (int fn = 0; fn < 4; ++fn) _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                     \
@@ -636,7 +647,7 @@ DEVI void w4_epilogue_lds(const f32x16 (&acc)[4][4], const W4Cols& cc, bool has_
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int row = it * RPI + rrow;
-            const int sw = (row & 15) << 1;
+            const int sw = swz(row);
             const char* rp = img + row * 512;
             const int s0 = gcol >> 2;
             a[it][0] = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ sw) << 4));
