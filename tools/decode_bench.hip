@@ -138,6 +138,10 @@ int main(int argc, char** argv) {
     const int part_cus = full ? (getenv("DOTS_BENCH_CUS") ? atoi(getenv("DOTS_BENCH_CUS")) : 128) : 0;      // the partition plan caps gate|up's grid at what the partition holds
     printf("decode attention: %s\n", decode_attn_stream_wgs(B, Hkv, n_splits, max_pages, part_cus) ? "streaming kernel (one resident workgroup per CU)" : "one workgroup per (row, kv head, split)");
     bf16_t* xn = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<bf16_t>((size_t)64 * H);      // scratch of the round-6 four-tile kernels (decode_b64.hip)
+    // DOTS_BENCH_SHARE_SMALL=1: every layer reads layer 0's qkv and o_proj weights (11 MB: resident in the XCDs' L2s after the first layer) while gate|up / down
+    // stay distinct — the UPPER BOUND of any scheme that prefetches the small kernels' weights into L2 ahead of their launch (VERDICT r5 #2b)
+    if (getenv("DOTS_BENCH_SHARE_SMALL")) { for (int i = 1; i < L; ++i) { qkv[i] = qkv[0]; o[i] = o[0]; } printf("qkv / o_proj weights shared by all layers (L2-resident)\n"); }
+    if (getenv("DOTS_BENCH_SHARE_ALL")) { for (int i = 1; i < L; ++i) { qkv[i] = qkv[0]; o[i] = o[0]; w13[i] = w13[0]; down[i] = down[0]; } printf("all layer weights shared (Infinity-Cache-resident)\n"); }
     auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, part_cus, xn)); };
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale, part_cus)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
