@@ -42,7 +42,8 @@ def test_a4_page_alone_and_in_the_packed_batch_against_the_full_depth_oracle_fix
     for mode in ("emu", "f32"):
         assert f"top_vals_{mode}" in fx.files, f"{FIX.name} is incomplete ({mode} half missing): re-run tools/make_a4_anchor.py"
     cfg = DotsConfig()
-    sd = random_state_dict(cfg, seed=0, threads=min(32, os.cpu_count() or 8))
+    from shared_weights import full_sd
+    sd = full_sd(0)
     proc = DotsOcrProcessor(cfg)
     msgs = bench.bench_messages("a4")
     pages = [preprocess_image(synth_page(i, A4_200DPI)) for i in range(8)]

@@ -211,7 +211,8 @@ def test_full_size_model_a4_pages_deterministic_and_batch_invariant():
     from dots_ocr_amd.synthetic import A4_200DPI, synth_page, synth_prompt_ids
     from dots_ocr_amd.weights import random_state_dict
     cfg = DotsConfig()
-    sd = random_state_dict(cfg, seed=0, threads=min(32, os.cpu_count() or 8))
+    from shared_weights import full_sd
+    sd = full_sd(0)
     eng = Engine(cfg, max_batch=2, max_seq_len=14600, max_patches=57600 + 64, max_prefill_tokens=14600)
     eng.load_state_dict(sd)
     del sd

@@ -85,10 +85,19 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     # time).  The fp32-oracle tolerance (max |logit err| <= 0.125) at this context length is asserted by tests/test_a4_anchor_gpu.py against a
     # committed full-depth oracle run — the oracle's OWN tower included — with no oracle time in the suite.
     n_steps, n_f32 = 64, 0
+    # ... and once that fixture holds 64 teacher-forced steps (tools/make_a4_anchor.py, N_STEPS = 64) the emulated pass below — 100 s of LM prefill + decode on
+    # the host for an LM-only comparison — is redundant too: the anchor test then holds the same 64 steps of the WHOLE path to the same token rule.  What
+    # stays here is everything only the GPU can say: step-by-step == graph replay, pipelined == sequential bit for bit, the peaked checkpoint.
+    try:
+        anchor_steps = int(np.load(ROOT / "tests" / "golden" / "a4_anchor.npz")["tokens_emu"].shape[0])
+    except Exception:
+        anchor_steps = 0
+    inline_oracle = anchor_steps < n_steps
     cfg = DotsConfig()
     threads = min(os.cpu_count() or 8, 64)
     torch.set_num_threads(threads)
-    sd = random_state_dict(cfg, seed=0, threads=min(32, os.cpu_count() or 8))
+    from shared_weights import F32View, full_sd
+    sd = full_sd(0)                                  # shared with the other full-size test modules of the session (never modified in place)
     pages = [preprocess_image(synth_page(i, A4_200DPI)) for i in range(4)]
     assert all(pv.shape[0] == 19824 for pv, _ in pages)
     prompts = [synth_prompt_ids(cfg, 19824 // 4, seed=i) for i in range(4)]
@@ -131,12 +140,15 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     rep["pipelined_vs_sequential"] = {"batches": 3, "pages_per_batch": 2, "tokens_per_page": NEW, "result": "bitwise equal"}
     eng.close()
 
-    lm_sd = {k: v.float() for k, v in sd.items() if not k.startswith("vision_tower.")}
+    lm_sd = F32View(sd, skip_prefix="vision_tower.")
     t_ids = torch.from_numpy(prompts[0].astype(np.int64))
     # (running the two oracle passes side by side in threads was tried: 271 s against 256 s one after the other — they share the cores)
     t0 = time.perf_counter()
-    _, emu_lg = om.generate(lm_sd, cfg, t_ids, None, None, n_steps, emulate_bf16=True, forced_tokens=eng_tokens, return_logits=True,
-                            vision_embeds=vis_f)
+    n_cmp = n_steps if inline_oracle else 0
+    emu_lg = []
+    if inline_oracle:
+        _, emu_lg = om.generate(lm_sd, cfg, t_ids, None, None, n_steps, emulate_bf16=True, forced_tokens=eng_tokens, return_logits=True,
+                                vision_embeds=vis_f)
     t1 = time.perf_counter()
     f32_lg = None
     if n_f32:
@@ -146,7 +158,7 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     rows, agree, outside, violations = _compare(eng_logits, eng_tokens, emu_lg, f32_lg)
     worst = max([r["max_abs_err_vs_fp32"] for r in rows[:n_f32]], default=0.0)
     rep.update({"input": f"one synthetic A4@200dpi page -> 19824 patches, {L} prompt tokens; engine sized as bench.py (25 KV splits)",
-                "steps": n_steps, "greedy_tokens_equal_to_emulated_oracle_argmax": agree, "steps_outside_the_near_tie_band": outside,
+                "steps": n_cmp, "inline_oracle_pass": inline_oracle, "greedy_tokens_equal_to_emulated_oracle_argmax": agree, "steps_outside_the_near_tie_band": outside,
                 "max_abs_logit_err_vs_fp32_oracle_first_%d_steps" % n_f32: worst,
                 "tolerance": "max |logit err| vs fp32 oracle <= 0.125; token == emulated oracle arg max at every step whose oracle top-2 margin > 2 x that "
                              "step's max |err vs emulated|; >= 2 such steps required at N(0, 0.02) weights (the peaked checkpoint below supplies 32 of 32)",
@@ -176,7 +188,7 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     n_p = 32
     vis_p, lg_p, tok_p = _step_by_step(eng_p, pv_s, thw_s, ids_s, cfg, n_p)
     eng_p.close()
-    lm_p = {k: v.float() for k, v in sd_p.items() if not k.startswith("vision_tower.")}
+    lm_p = F32View(sd_p, skip_prefix="vision_tower.")      # the planted tensors are converted here, the untouched ones reuse the session's fp32 copies
     del sd, sd_p
     _, emu_p = om.generate(lm_p, cfg, torch.from_numpy(ids_s.astype(np.int64)), None, None, n_p, emulate_bf16=True, forced_tokens=tok_p, return_logits=True,
                            vision_embeds=vis_p)
@@ -197,8 +209,9 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     assert not violations, f"engine token != emulated oracle arg max outside the near-tie band: {violations[:4]}"
     # N(0, 0.02) weights give top-2 margins of 0.02-0.10 against a worst-case error (max over 151 936 logits) of 0.05-0.06: only a handful of the
     # 128 steps lie outside the band (4 measured) — the teeth of the token rule are the peaked checkpoint below, where every step does
-    assert outside >= 1, f"only {outside} of {n_steps} steps lie outside the near-tie band"
-    assert agree >= n_steps - 6
+    if inline_oracle:
+        assert outside >= 1, f"only {outside} of {n_steps} steps lie outside the near-tie band"
+        assert agree >= n_steps - 6
     assert not viol_p, f"peaked checkpoint: token mismatch outside the near-tie band: {viol_p[:4]}"
     assert outside_p >= n_p * 3 // 4, f"peaked checkpoint: only {outside_p} of {n_p} steps have a margin above 2 x error"
     assert len(set(tok_p)) >= n_p // 2, f"peaked checkpoint: only {len(set(tok_p))} distinct tokens in {n_p} steps"

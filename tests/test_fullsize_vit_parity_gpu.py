@@ -38,12 +38,12 @@ def _bf(u16):
 @pytest.fixture(scope="module")
 def world():
     from dots_ocr_amd.config import DotsConfig
-    from dots_ocr_amd.weights import random_state_dict
+    from shared_weights import F32View, full_sd
     cfg = DotsConfig()
     threads = min(os.cpu_count() or 8, 64)
     torch.set_num_threads(threads)
-    sd = random_state_dict(cfg, seed=0, threads=min(32, os.cpu_count() or 8))
-    sd32 = {k: v.float() for k, v in sd.items()}
+    sd = full_sd(0)                              # shared with the other full-size test modules of the session (never modified in place)
+    sd32 = F32View(sd)                           # fp32 on first use, kept for the session
     yield cfg, sd, sd32
     out = ROOT / "gpurun_out"
     try:

@@ -79,12 +79,13 @@ def test_planted_walk_tokens_are_decided_by_the_layer_stack_bf16_and_fp8():
     cfg = DotsConfig()
     threads = min(os.cpu_count() or 8, 64)
     torch.set_num_threads(threads)
-    sd = random_state_dict(cfg, seed=0, threads=min(32, threads))
+    from shared_weights import F32View, full_sd
+    sd = dict(full_sd(0))                        # a private dict over the session's shared tensors: only lm_head is replaced below (never modified in place)
     g = torch.Generator().manual_seed(11)
     prompt = torch.randint(1000, 100000, (PROMPT,), generator=g)
     walk = torch.randperm(100000, generator=g)[:N_STEPS] + 1000          # distinct, no special / image token ids
     assert cfg.image_token_id not in set(prompt.tolist()) | set(walk.tolist())
-    lm = {k: v.float() for k, v in sd.items() if not k.startswith("vision_tower.")}
+    lm = dict(F32View(sd, skip_prefix="vision_tower."))     # fp32 copies shared with the other full-size tests of the session
     planted, ratios = plant_walk(lm, cfg, prompt, walk)
     head = sd["lm_head.weight"].clone()
     head[walk] = planted.to(head.dtype)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/a4_anchor.npz: ONE full-depth pass of the CPU oracle (oracle/model.py: 42 vision blocks at 19 824 patches,
-28 LM layers over the 5 200-token bench prompt, 16 greedy steps) over synthetic A4 page 0 + the prompt bench.py gives page 0, in BOTH
+28 LM layers over the 5 200-token bench prompt, 64 greedy steps) over synthetic A4 page 0 + the prompt bench.py gives page 0, in BOTH
 oracle modes, reduced to what a GPU test needs (VERDICT r5 "next" #4: whole-path parity at the benchmark size with no oracle time in the
 GPU suite).  Reference path restated by the oracle: dots_ocr/parser.py:99-116.
 
@@ -8,7 +8,7 @@ GPU suite).  Reference path restated by the oracle: dots_ocr/parser.py:99-116.
 
 Kept per mode (emulated-bf16 = the engine's rounding points, fp32 = truth for tolerances):
   vis_rows[256]                the sampled merged-vision row indices (seeded), vis_<mode> their values, vis_absmax_<mode> the tensor's max |x|
-  tokens_emu[16], margins_emu  the emulated oracle's free-running greedy tokens and its top-2 margin at each step
+  tokens_emu[64], margins_emu  the emulated oracle's free-running greedy tokens and its top-2 margin at each step
   then both modes TEACHER-FORCED on tokens_emu, per step s:
   top_ids_<mode>[s, 32], top_vals_<mode>[s, 32]     the 32 largest logits
   probe_ids[2048], probe_<mode>[s, 2048]            logits at a fixed seeded sample of the vocabulary
@@ -33,8 +33,8 @@ from dots_ocr_amd.synthetic import A4_200DPI, synth_page  # noqa: E402
 from dots_ocr_amd.weights import random_state_dict  # noqa: E402
 from oracle import model as om  # noqa: E402
 
-N_STEPS, N_ROWS, N_TOP, N_PROBE = 16, 256, 32, 2048
-OUT = ROOT / "tests" / "golden" / "a4_anchor.npz"
+N_STEPS, N_ROWS, N_TOP, N_PROBE = 64, 256, 32, 2048
+OUT = Path(os.environ.get("DOTS_ANCHOR_OUT", str(ROOT / "tests" / "golden" / "a4_anchor.npz")))
 
 
 def main():
@@ -57,10 +57,26 @@ def main():
     secs = []
     for mode, emu in (("emu", True), ("f32", False)):
         t0 = time.perf_counter()
-        with torch.no_grad():
-            vis = om.vision_tower(sd32, cfg, t_pv, t_thw, emulate_bf16=emu)
+        cache = Path(os.environ.get("DOTS_ANCHOR_CACHE", "/tmp/anchor")) / f"vis_{mode}.pt"      # the towers are the expensive part: a rerun with more steps reuses them
+        t_tower_prev = None
+        if cache.exists():
+            vis = torch.load(cache)
+            try:                                                 # keep the tower time of the run that computed it
+                t_tower_prev = float(np.load(ROOT / "tests" / "golden" / "a4_anchor.npz")["seconds"][0 if emu else 2])
+            except Exception:
+                pass
+        else:
+            with torch.no_grad():
+                vis = om.vision_tower(sd32, cfg, t_pv, t_thw, emulate_bf16=emu)
+            try:
+                cache.parent.mkdir(parents=True, exist_ok=True)
+                torch.save(vis, cache)
+            except OSError:
+                pass
         t1 = time.perf_counter()
-        print(f"[{mode}] tower {t1 - t0:.0f} s", flush=True)
+        if t_tower_prev is not None:
+            t0 = t1 - t_tower_prev
+        print(f"[{mode}] tower {t1 - t0:.0f} s" + (" (cached rows of an earlier run)" if t_tower_prev is not None else ""), flush=True)
         rec[f"vis_{mode}"] = vis[torch.from_numpy(rows.astype(np.int64))].numpy().astype(np.float32)
         rec[f"vis_absmax_{mode}"] = np.asarray([float(vis.abs().max())], np.float32)
         toks, logits = om.generate(sd32, cfg, t_ids, None, None, N_STEPS, emulate_bf16=emu, forced_tokens=forced, return_logits=True, vision_embeds=vis)
