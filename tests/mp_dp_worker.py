@@ -65,6 +65,7 @@ def main():
     device = 0 if os.environ.get("DOTS_TEST_DP_ONE_GPU") else local
     torch.cuda.set_device(device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: no interface / hostname discovery (the box's hostname may not resolve: tens of seconds of time-outs)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
     else:
