@@ -760,8 +760,8 @@ def main():
                 vit_tflops = lastst["vit_flops"] * n / vit_s / 1e12 if vit_s > 0 else 0.0
                 r = {"bound": "mfma", "kernel": "flash_attn64_kernel (ViT bidirectional var-len attention; 4 waves x 64 query rows, round 4)",
                      "achieved": attn_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": attn_tflops / PEAK_BF16_TFLOPS,
-                     "traffic": recorded("r04_flash_attn_traffic.json", "traffic_bytes_per_launch"),
-                     "traffic_unit": "bytes/launch (PMC on the whole chip, profiles/r04_flash_attn_traffic.json)",
+                     "traffic": recorded("r06_flash_attn_traffic.json", "traffic_bytes_per_launch"),
+                     "traffic_unit": "bytes/launch (PMC on the whole chip, profiles/r06_flash_attn_traffic.json: 4.31 GB against 1.95 GB compulsory, unchanged since round 4)",
                      "algorithmic_flops_per_launch": lastst["vit_attn_flops"] / max(1, lastst["vit_attn_launches"]),
                      "launches_per_step": lastst["vit_attn_launches"],
                      "avg_launch_ms": ph["vit_attn_ms"] / n / max(1, lastst["vit_attn_launches"])}
@@ -783,9 +783,10 @@ def main():
                                   "(half-chip launch plan); the step alone on the whole chip is in roofline_decode_sequential")
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
                     if deep:                       # the B = 8 whole-chip figure describes roofline_decode_sequential; the 64-row partition step has its own PMC pass (round 5)
-                        rd["traffic"] = recorded("r05_decode_traffic_64rows.json", "traffic_bytes_per_decode_step") if rif == 64 and a.workload == "a4" else None
-                        rd["traffic_unit"] = ("bytes per decode step (PMC, 64 rows on the 64-CU partition plan, profiles/r05_decode_traffic_64rows.json: 1.24 x the "
-                                              "algorithmic bytes — gate|up and lm_head pass their weights through the L2s twice, once per pair of batch tiles)"
+                        rd["traffic"] = recorded("r06_decode_traffic_64rows.json", "traffic_bytes_per_decode_step") if rif == 64 and a.workload == "a4" else None
+                        rd["traffic_unit"] = ("bytes per decode step (PMC, 64 rows on the 64-CU partition plan, profiles/r06_decode_traffic_64rows.json: 1.10 x the "
+                                              "algorithmic bytes (round 5: 1.24) — gate|up and lm_head now pass their weights through the CUs once; what is left are "
+                                              "the X images the projections re-read and the attention partials)"
                                               if rd["traffic"] else "not measured for the %d-row step (PMC traffic at B = 8: roofline_decode_sequential.traffic)" % rif)
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8
