@@ -186,7 +186,7 @@ def other_config_legs():
     engine, its own parity check — a leg that is not parity-clean exits non-zero and is reported as failed); the headline keys of the a4 line are
     untouched.  About 60 s in all."""
     import subprocess
-    legs = [("highres", ["--workload", "highres", "--steps", "6", "--warmup", "3"]),      # (the adaptive tower tail settles within the warm-up steps: 3 / 1 measured 11.1 pages/s against 14.4 at 5 / 2)
+    legs = [("highres", ["--workload", "highres", "--batch", "4", "--steps", "8", "--warmup", "4"]),      # configs[2]: batch = 4      # (the adaptive tower tail settles within the warm-up steps: 3 / 1 measured 11.1 pages/s against 14.4 at 5 / 2)
             ("mixed64", ["--workload", "mixed64", "--steps", "1", "--warmup", "0"]),
             ("svg_fp8", ["--workload", "svg", "--steps", "1", "--warmup", "1"])]
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "output_tok_s", "roofline", "roofline_decode", "roofline_decode_sequential",
@@ -829,11 +829,11 @@ def main():
                 # the three shapes of the same work side by side: throughput AND how long a page waits for its tokens
                 step_ms = dt / K * 1e3
                 one = None
-                f1 = ROOT / "profiles" / "r05_bench_a4_one_batch_in_flight.json"
+                f1 = ROOT / "profiles" / "r06_bench_a4_one_batch_in_flight.json"
                 if a.workload == "a4" and B == 8 and f1.exists():
                     j1 = json.loads(f1.read_text())
                     one = {"pages_per_s": j1["value"], "page_latency_s": 2 * j1["ms_per_step"] / 1e3,
-                           "source": "profiles/r05_bench_a4_one_batch_in_flight.json (bench.py --rows-in-flight 8 on the same build: the tower of batch k+1 beside the decode loop of batch k)"}
+                           "source": "profiles/r06_bench_a4_one_batch_in_flight.json (bench.py --rows-in-flight 8 on the same build: the tower of batch k+1 beside the decode loop of batch k)"}
                 res["throughput_shapes"] = {
                     "headline": f"pipelined, {rif if deep else B} rows in flight",
                     f"pipelined_{rif if deep else B}_rows_in_flight": {"pages_per_s": pages_total / dt, "page_latency_s": (n_groups if deep else 2) * step_ms / 1e3,
