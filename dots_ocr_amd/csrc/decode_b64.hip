@@ -33,13 +33,142 @@ constexpr int S64_NBUF = 3;      // X chunk ring
 enum { S64_GATEUP = 0, S64_LMHEAD = 1 };
 
 // rows [B, H] -> rmsnorm -> X image [ceil(B / 16)][H / 8][16][8] in global memory.  One wave per row; bits of dec_*_kernel's prologue.
-__global__ __launch_bounds__(256) void dec_norm_ximg_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w, bf16_t* __restrict__ xn,
-                                                            int B, int H, float eps) {
+// PART (round 6, the K-half down_proj below): the rows are not final yet — the projection left its two K-half sums in `part` ([2][64][H] fp32) instead of
+// adding them to the residual stream.  This kernel does that first, with proj_epilogue's own arithmetic (lo + hi, x the fp8 weight scale, + residual, one
+// rounding to bf16), writes the rows back to h and normalises what it wrote.  xn == nullptr: only the residual update (the single-kernel test entry).
+template <bool PART>
+__global__ __launch_bounds__(256) void dec_norm_ximg_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w, bf16_t* __restrict__ xn,
+                                                            const float* __restrict__ part, const float* __restrict__ pscale, int B, int H, float eps) {
+#pragma clang fp contract(off)      // the residual update must round exactly like proj_epilogue (decode_fused.hip)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wave_id();                                     // wave-uniform
     Rows<1, NC_MAX> R;
-    rows_issue<1, NC_MAX>(R, h, ln_w, B, H, r, 0, lane);
-    if (r < B) row_norm_to_lds<NC_MAX>(R.v[0], R.w, r & 15, H, eps, xn + (size_t)(r >> 4) * 16 * H, 16, lane);
+    rows_issue<1, NC_MAX>(R, h, ln_w ? ln_w : h, B, H, r, 0, lane);
+    if constexpr (PART) {
+        if (r < B) {
+#pragma unroll
+            for (int c = 0; c < NC_MAX; ++c) {
+                const int k = c * 512 + lane * 8;
+                if (k < H) {
+                    const float* p0 = part + (size_t)r * H + k;
+                    const float* p1 = p0 + (size_t)MAX_DECODE_ROWS * H;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0), a1 = *reinterpret_cast<const f32x4*>(p0 + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1), b1 = *reinterpret_cast<const f32x4*>(p1 + 4);
+                    f32x4 s0 = a0 + b0, s1 = a1 + b1;                             // lo + hi
+                    if (pscale) {
+                        s0 *= *reinterpret_cast<const f32x4*>(pscale + k);
+                        s1 *= *reinterpret_cast<const f32x4*>(pscale + k + 4);
+                    }
+                    const u32x4 res = R.v[0][c];
+                    const u32x4 o = {pack_bf2(lo_bf(res[0]) + s0[0], hi_bf(res[0]) + s0[1]), pack_bf2(lo_bf(res[1]) + s0[2], hi_bf(res[1]) + s0[3]),
+                                     pack_bf2(lo_bf(res[2]) + s1[0], hi_bf(res[2]) + s1[1]), pack_bf2(lo_bf(res[3]) + s1[2], hi_bf(res[3]) + s1[3])};
+                    R.v[0][c] = o;
+                    *reinterpret_cast<u32x4*>(h + (size_t)r * H + k) = o;
+                }
+            }
+        }
+    }
+    if (xn && r < B) row_norm_to_lds<NC_MAX>(R.v[0], R.w, r & 15, H, eps, xn + (size_t)(r >> 4) * 16 * H, 16, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// down_proj above 32 rows as TWO K halves (round 6).  dec_proj_wide_kernel (decode_fused.hip) gives a workgroup a few output features over the FULL K, so
+// every workgroup reads the WHOLE X image — 64 x 8960 x 2 B = 1.15 MB beside its 0.43 MB of weights on the 64-CU partition, 1.15 MB beside 143 KB on the
+// whole chip — and a CU pulls ~50 GB/s whatever the source (profiles/r06_decode_trace_b64.txt): the kernel sat on that line.  Here a workgroup owns ONE half
+// of K (slices 0-7 or 8-15 of the same 16 slices, same boundaries) for twice the features: half the X bytes per workgroup, the same weight bytes.  Its 8
+// waves (one slice each, all features of the workgroup: NM MFMAs of 16 weight rows x 4 batch tiles per k-step, 256 registers per lane) reduce their slice
+// sums in order through LDS and store the half's fp32 sum to part[half][row][col]; the consumer of the residual stream — always a norm kernel at these
+// batch sizes — adds lo + hi, the fp8 scale and the residual exactly as proj_epilogue does (dec_norm_ximg_kernel<true>).  Every projection kernel adds its
+// 16 slice sums as (s0 + .. + s7) + (s8 + .. + s15) since this round (proj_sum16), so a row's bits do not depend on which kernel ran.
+constexpr int KH_G = 4;              // k-steps per round: KH_G x (NM weight + 4 activation fragments) requested together
+template <int NM, typename WT>
+__global__ __launch_bounds__(512) void dec_proj_khalf_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, float* __restrict__ part,
+                                                             int B, int N, int K, int NU) {
+    constexpr int TT = S64_TT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                                  // [8 slices][NM][TT][64]
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const int m = lane & 15, g = lane >> 4;
+    const int half = blockIdx.x, n_tiles = (B + 15) >> 4, n_units = N >> 3;
+    const int u0 = blockIdx.y * NU;
+    const int KS = K / 32, sl = 8 * half + wv;
+    const int k0 = (int)((uint32_t)(sl * KS) >> 4), k1 = (int)((uint32_t)((sl + 1) * KS) >> 4);       // the 16-slice boundaries of dec_proj_kernel
+    uint32_t woff[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int ua = min(u0 + 2 * j, n_units - 1);
+        const int ub = (2 * j + 1 < NU && u0 + 2 * j + 1 < n_units) ? u0 + 2 * j + 1 : ua;
+        const int u = (m >> 3) ? ub : ua;
+        woff[j] = (uint32_t)(((size_t)(u >> 1) * KS * 64 + lane_slot<WT>(g, (m & 7) + 8 * (u & 1))) * sizeof(WT));
+    }
+    const char* wbase = reinterpret_cast<const char*>(Wd);
+    const char* zbase = reinterpret_cast<const char*>(g_zero_chunk);
+    const uint32_t zoff = lane * (uint32_t)sizeof(WT);
+    const char* xbase = reinterpret_cast<const char*>(X);
+    const uint32_t xoff = lane * 16u;
+    uint32_t toff[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) toff[t] = (uint32_t)min(t, n_tiles - 1) * 32u * (uint32_t)K;
+    TRACE(0);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {                                           // the even chain, then the odd chain (dec_proj_kernel: acc0 / acc1)
+        f32x4 acc[NM][TT];
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+        for (int kb = k0 + par; kb < k1; kb += 2 * KH_G) {                        // wave-uniform trip count
+            WT a[NM][KH_G];
+            bf16x8 b[TT][KH_G];
+#pragma unroll
+            for (int jj = 0; jj < KH_G; ++jj) {
+                const int k = kb + 2 * jj;
+                const bool ok = k < k1;                                           // slots past the slice multiply a chunk of zeros
+                const int kc = min(k, KS - 1);
+                const char* wk = ok ? wbase + (size_t)k * 64 * sizeof(WT) : zbase;
+#pragma unroll
+                for (int j = 0; j < NM; ++j) a[j][jj] = __builtin_nontemporal_load(reinterpret_cast<const WT*>(wk + (ok ? woff[j] : zoff)));
+#pragma unroll
+                for (int t = 0; t < TT; ++t) b[t][jj] = *reinterpret_cast<const bf16x8*>(xbase + (size_t)(toff[t] + (uint32_t)kc * 1024u) + xoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < KH_G; ++jj)
+#pragma unroll
+                for (int j = 0; j < NM; ++j) {
+                    const bf16x8 wa = as_a(a[j][jj]);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, b[t][jj], acc[j][t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4* rp = red + ((size_t)((wv * NM + j) * TT + t)) * 64 + lane;
+                if (par == 0) *rp = acc[j][t];
+                else *rp = *rp + acc[j][t];                                       // even + odd
+            }
+    }
+    TRACE(1);
+    __syncthreads();
+    TRACE(2);
+    // accumulator tile e = (MFMA je, batch tile te): wave wv finishes tiles wv, wv + 8
+#pragma unroll
+    for (int i = 0; i < (NM * TT + 7) / 8; ++i) {
+        const int e = wv + 8 * i;
+        if (e >= NM * TT) break;                                                  // wave-uniform
+        const int je = e / TT, te = e % TT;
+        const int ul = 2 * je + (g >> 1), unit = u0 + ul, row = 16 * te + m;
+        if (ul < NU && unit < n_units && row < B) {
+            f32x4 p = {0, 0, 0, 0};
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) p += red[((size_t)((s8 * NM + je) * TT + te)) * 64 + lane];      // this half of proj_sum16
+            *reinterpret_cast<f32x4*>(part + ((size_t)half * MAX_DECODE_ROWS + row) * N + 8 * unit + 4 * (g & 1)) = p;
+        }
+    }
+    TRACE(3);
 }
 
 // SwiGLU of one lane's 4 features of a (gate, up) accumulator pair -> X image.  The expression of dec_gateup_kernel's epilogue.
@@ -304,26 +433,54 @@ bool dec_stream64_supports(int B, int H) {
     return !off && B > 32 && B <= MAX_DECODE_ROWS && (H == 128 * 12 || H == 128 * 6);       // K chunk = 12 k-steps (dots.ocr) or 6 (the tests' small model)
 }
 
-hipError_t launch_dec_norm_ximg(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, bf16_t* xn, int B, int H, float eps) {
-    if (H % 8 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_norm_ximg_kernel, dim3((B + 3) / 4), dim3(256), 0, s, h, ln_w, xn, B, H, eps);
+hipError_t launch_dec_norm_ximg(hipStream_t s, const bf16_t* h_in, const bf16_t* ln_w, bf16_t* xn, int B, int H, float eps, const float* part, const float* pscale) {
+    bf16_t* h = const_cast<bf16_t*>(h_in);                    // written only when `part` is given (the pending residual update of a K-half projection)
+    if (H % 8 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS || (!xn && !part)) return hipErrorInvalidValue;
+    if (part) hipLaunchKernelGGL(dec_norm_ximg_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, s, h, ln_w, xn, part, pscale, B, H, eps);
+    else hipLaunchKernelGGL(dec_norm_ximg_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, s, h, ln_w, xn, part, pscale, B, H, eps);
     return hipGetLastError();
+}
+
+// down_proj above 32 rows as two K halves: part[2][64][N] <- the halves' slice sums (h is NOT updated: launch_dec_norm_ximg(.., part, wscale) does that).
+bool dec_proj_khalf_supports(int B, int N, int K) {
+    static const bool off = getenv("DOTS_OCR_DEC_KHALF") && atoi(getenv("DOTS_OCR_DEC_KHALF")) == 0;      // A/B switch: dec_proj_wide_kernel over the full K
+    return !off && B > 32 && B <= MAX_DECODE_ROWS && N % 16 == 0 && N <= 512 * NC_MAX && K % 32 == 0 && K / 32 >= 64;      // long K only (o_proj's X image is 192 KB); N: what the norm kernel's rows hold
+}
+
+hipError_t launch_dec_proj_khalf(hipStream_t s, const bf16_t* X, const void* Wd, bool fp8, float* part, int B, int N, int K, int cus) {
+    if (!dec_proj_khalf_supports(B, N, K) || !part) return hipErrorInvalidValue;
+    if (cus <= 0) cus = device_cus();
+    static uint32_t attr[6] = {0, 0, 0, 0, 0, 0};
+    const int n_units = N / 8;
+    // 2 K halves x ceil(n_units / nu) workgroups in ONE round on the CUs the stream may use; a workgroup takes up to 6 units (3 MFMAs of 16 weight rows)
+    const int nu = std::max(1, std::min(6, (2 * n_units + cus - 1) / cus)), nm = (nu + 1) / 2;
+    const size_t lds = (size_t)8 * nm * S64_TT * 64 * sizeof(f32x4);
+    const dim3 grid(2, (n_units + nu - 1) / nu);
+    auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
+        hipError_t e = ensure_lds64(kern, lds, done);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, X, wd, part, B, N, K, nu);
+        return hipGetLastError();
+    };
+    if (nm == 1) return fp8 ? go(dec_proj_khalf_kernel<1, u32x2>, (const u32x2*)Wd, &attr[0]) : go(dec_proj_khalf_kernel<1, bf16x8>, (const bf16x8*)Wd, &attr[1]);
+    if (nm == 2) return fp8 ? go(dec_proj_khalf_kernel<2, u32x2>, (const u32x2*)Wd, &attr[2]) : go(dec_proj_khalf_kernel<2, bf16x8>, (const bf16x8*)Wd, &attr[3]);
+    return fp8 ? go(dec_proj_khalf_kernel<3, u32x2>, (const u32x2*)Wd, &attr[4]) : go(dec_proj_khalf_kernel<3, bf16x8>, (const bf16x8*)Wd, &attr[5]);
 }
 
 // act = silu(gate) * up of rmsnorm(h), B in (32, 64]: norm kernel -> xn (scratch: 64 x H bf16), then the streaming kernel.  cus: CUs the stream may use.
 hipError_t launch_dec_gateup64(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act, bf16_t* xn,
-                               int B, int H, int I, float eps, int cus) {
+                               int B, int H, int I, float eps, int cus, const float* pend, const float* pend_scale) {
     if (!dec_stream64_supports(B, H) || I % 32 || !xn) return hipErrorInvalidValue;
-    HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps));
+    HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps, pend, pend_scale));
     if (cus <= 0) cus = device_cus();
     return wscale ? stream64_launch<S64_GATEUP>(s, xn, (const u32x2*)W13d, wscale, act, B, H, I, I / 16, cus)
                   : stream64_launch<S64_GATEUP>(s, xn, (const bf16x8*)W13d, wscale, act, B, H, I, I / 16, cus);
 }
 
 hipError_t launch_dec_lmhead64(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits, bf16_t* xn,
-                               int B, int H, int V, float eps, int cus) {
+                               int B, int H, int V, float eps, int cus, const float* pend, const float* pend_scale) {
     if (!dec_stream64_supports(B, H) || V % 16 || !xn) return hipErrorInvalidValue;
-    HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps));
+    HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps, pend, pend_scale));
     if (cus <= 0) cus = device_cus();
     const int n_items = (V / 16 + 1) / 2;
     return wscale ? stream64_launch<S64_LMHEAD>(s, xn, (const u32x2*)Wd, wscale, logits, B, H, V, n_items, cus)

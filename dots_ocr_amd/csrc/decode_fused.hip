@@ -174,6 +174,18 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     TRACE(6);
 }
 
+// ---- split-K reduction of a projection: the 16 slice sums as TWO halves, each added in slice order from zero, then lo + hi (round 6: until then one
+// chain of 16).  The K-half kernel of decode_b64.hip computes `lo` and `hi` in two different workgroups (each needs only its half of the X image) and the
+// norm kernel that consumes the residual stream adds them — so every projection kernel uses this order: a row's bits must not depend on the kernel that ran.
+DEVI f32x4 proj_sum16(const f32x4* red, int stride) {
+    f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) lo += red[(size_t)sl * stride];
+#pragma unroll
+    for (int sl = 8; sl < 16; ++sl) hi += red[(size_t)sl * stride];
+    return lo + hi;
+}
+
 // ---- residual epilogue of one lane of a projection: h[row][col0 .. col0 + 3] = bf16(residual + sum * scale).  One definition for the
 // projection kernels (a row's bits must not depend on the batch it shares, i.e. on which of them ran).
 template <typename WT>
@@ -250,9 +262,7 @@ __global__ __launch_bounds__(1024) void dec_proj_kernel(const bf16_t* __restrict
     __syncthreads();
     TRACE(2);
     if (!epi) return;
-    f32x4 s = {0, 0, 0, 0};
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) s += red[sl * 64 + lane];
+    const f32x4 s = proj_sum16(red + lane, 64);
     proj_epilogue<WT>(hp, res, s, sc);
     TRACE(3);
 }
@@ -316,9 +326,7 @@ __global__ __launch_bounds__(1024) void dec_proj_lds_kernel(const bf16_t* __rest
     __syncthreads();
     TRACE(2);
     if (!epi) return;
-    f32x4 sum = {0, 0, 0, 0};
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) sum += red[sl * 64 + lane];
+    const f32x4 sum = proj_sum16(red + lane, 64);
     proj_epilogue<WT>(hp, res, sum, sc);
     TRACE(3);
 }
@@ -478,9 +486,7 @@ __global__ __launch_bounds__(1024) void dec_proj_wide_kernel(const bf16_t* __res
     __syncthreads();
     TRACE(2);
     if (!epi) return;
-    f32x4 sum = {0, 0, 0, 0};
-#pragma unroll
-    for (int sl = 0; sl < 16; ++sl) sum += red[((size_t)((sl * NM + je) * TT + te)) * 64 + lane];
+    const f32x4 sum = proj_sum16(red + ((size_t)(je * TT + te)) * 64 + lane, NM * TT * 64);
     proj_epilogue<WT>(hp, res, sum, sc);
     TRACE(3);
 }
@@ -983,15 +989,23 @@ static bool wide_on() {
 // (half as many workgroups) at B <= 16, as many features per workgroup as one round on those CUs needs above.
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
-                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus, bf16_t* xn) {
+                          bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus, bf16_t* xn,
+                          const float* pend, const float* pend_scale) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int full_tiles = part_cus > 0;
+    {   // a pending K-half residual update that the X-image path below will not fuse into its norm launch gets a launch of its own
+        static const bool ximg_on0 = !(getenv("DOTS_OCR_QKV_XIMG") && atoi(getenv("DOTS_OCR_QKV_XIMG")) == 0);
+        if (pend && !(B > 16 && wide_on() && xn && B > 32 && ximg_on0)) {
+            HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));
+            pend = nullptr;
+        }
+    }
     if (B > 16 && wide_on()) {
         static uint32_t attr_w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // round 6, above 32 rows: the rows are normalised once by a small kernel (X image in xn) instead of by every workgroup
         static const bool ximg_on = !(getenv("DOTS_OCR_QKV_XIMG") && atoi(getenv("DOTS_OCR_QKV_XIMG")) == 0);     // A/B switch
         const bool ximg = xn && B > 32 && ximg_on;
-        if (ximg) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps));
+        if (ximg) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, ln_w, xn, B, H, eps, pend, pend_scale));
         const int n_out = (Hq + 2 * Hkv) * 8, cus = wide_cus(part_cus);
         const int nm = (n_out + cus - 1) / cus >= 2 ? 2 : 1, tt = B <= 32 ? 2 : 4;
         const size_t lds_w = (size_t)16 * nm * tt * 64 * sizeof(f32x4) + MAX_DECODE_ROWS * sizeof(float);
@@ -1037,8 +1051,14 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
 }
 
 // part_cus: see launch_dec_qkv
-hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus) {
+hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus,
+                           float* part, bool* pending) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
+    if (pending) *pending = false;
+    if (part && pending && wide_on() && dec_proj_khalf_supports(B, N, K)) {          // round 6: two K halves, the residual update is the consumer's (decode_b64.hip)
+        *pending = true;
+        return launch_dec_proj_khalf(s, X, Wd, wscale != nullptr, part, B, N, K, wide_cus(part_cus));
+    }
     const int full_tiles = part_cus > 0;
     if (B > 16 && wide_on()) {
         static uint32_t attr_w[16] = {0};
@@ -1196,9 +1216,10 @@ static hipError_t lmhead_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
 }
 
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
-                             int B, int H, int V, float eps, int part_cus, bf16_t* xn) {
+                             int B, int H, int V, float eps, int part_cus, bf16_t* xn, const float* pend, const float* pend_scale) {
     if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
-    if (xn && dec_stream64_supports(B, H) && H % (32 * 8) == 0) return launch_dec_lmhead64(s, h, ln_w, Wd, wscale, logits, xn, B, H, V, eps, wide_cus(part_cus));
+    if (xn && dec_stream64_supports(B, H) && H % (32 * 8) == 0) return launch_dec_lmhead64(s, h, ln_w, Wd, wscale, logits, xn, B, H, V, eps, wide_cus(part_cus), pend, pend_scale);
+    if (pend) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));      // the pending K-half residual update, by a launch of its own
     return wscale ? lmhead_launch(s, h, ln_w, (const u32x2*)Wd, wscale, logits, B, H, V, eps)
                   : lmhead_launch(s, h, ln_w, (const bf16x8*)Wd, wscale, logits, B, H, V, eps);
 }
