@@ -16,7 +16,7 @@
 //     ones on another, their sum (dec_lmhead_kernel) — so a row's bits do not depend on the batch it shares
 //     (tests/test_decode_kernels_gpu.py: the 40- / 64-row calls equal calls of <= 16 rows bit for bit).
 // Every wave of a workgroup runs the same instruction stream (a wave without a work item streams a chunk of zeros: its MFMAs add +0),
-// so the counted `s_waitcnt vmcnt` in front of each barrier is exact: the youngest 2 D memory operations are always ring loads.
+// so the counted `s_waitcnt vmcnt` in front of each barrier is exact: what was issued behind a chunk's DMA pieces is known at compile time.
 #include <algorithm>
 #include <cstdlib>
 
@@ -33,8 +33,8 @@ constexpr int S64_NBUF = 3;      // X chunk ring
 enum { S64_GATEUP = 0, S64_LMHEAD = 1 };
 
 // rows [B, H] -> rmsnorm -> X image [ceil(B / 16)][H / 8][16][8] in global memory.  One wave per row; bits of dec_*_kernel's prologue.
-// PART (round 6, the K-half down_proj below): the rows are not final yet — the projection left its two K-half sums in `part` ([2][64][H] fp32) instead of
-// adding them to the residual stream.  This kernel does that first, with proj_epilogue's own arithmetic (lo + hi, x the fp8 weight scale, + residual, one
+// PART (round 6, the K-split projections below): the rows are not final yet — the projection left its four K-quarter sums in `part` ([4][64][H] fp32) instead of
+// adding them to the residual stream.  This kernel does that first, with proj_epilogue's own arithmetic ((q0 + q1) + (q2 + q3), x the fp8 weight scale, + residual, one
 // rounding to bf16), writes the rows back to h and normalises what it wrote.  xn == nullptr: only the residual update (the single-kernel test entry).
 template <bool PART>
 __global__ __launch_bounds__(256) void dec_norm_ximg_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ ln_w, bf16_t* __restrict__ xn,
@@ -50,11 +50,14 @@ __global__ __launch_bounds__(256) void dec_norm_ximg_kernel(bf16_t* __restrict__
             for (int c = 0; c < NC_MAX; ++c) {
                 const int k = c * 512 + lane * 8;
                 if (k < H) {
-                    const float* p0 = part + (size_t)r * H + k;
-                    const float* p1 = p0 + (size_t)MAX_DECODE_ROWS * H;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p0), a1 = *reinterpret_cast<const f32x4*>(p0 + 4);
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p1), b1 = *reinterpret_cast<const f32x4*>(p1 + 4);
-                    f32x4 s0 = a0 + b0, s1 = a1 + b1;                             // lo + hi
+                    f32x4 q0[DEC_KSPLIT_PARTS], q1[DEC_KSPLIT_PARTS];
+#pragma unroll
+                    for (int i = 0; i < DEC_KSPLIT_PARTS; ++i) {
+                        const float* pp = part + ((size_t)i * MAX_DECODE_ROWS + r) * H + k;
+                        q0[i] = *reinterpret_cast<const f32x4*>(pp);
+                        q1[i] = *reinterpret_cast<const f32x4*>(pp + 4);
+                    }
+                    f32x4 s0 = (q0[0] + q0[1]) + (q0[2] + q0[3]), s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);      // proj_sum16's last three additions
                     if (pscale) {
                         s0 *= *reinterpret_cast<const f32x4*>(pscale + k);
                         s1 *= *reinterpret_cast<const f32x4*>(pscale + k + 4);
@@ -72,26 +75,28 @@ __global__ __launch_bounds__(256) void dec_norm_ximg_kernel(bf16_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// down_proj above 32 rows as TWO K halves (round 6).  dec_proj_wide_kernel (decode_fused.hip) gives a workgroup a few output features over the FULL K, so
-// every workgroup reads the WHOLE X image — 64 x 8960 x 2 B = 1.15 MB beside its 0.43 MB of weights on the 64-CU partition, 1.15 MB beside 143 KB on the
-// whole chip — and a CU pulls ~50 GB/s whatever the source (profiles/r06_decode_trace_b64.txt): the kernel sat on that line.  Here a workgroup owns ONE half
-// of K (slices 0-7 or 8-15 of the same 16 slices, same boundaries) for twice the features: half the X bytes per workgroup, the same weight bytes.  Its 8
-// waves (one slice each, all features of the workgroup: NM MFMAs of 16 weight rows x 4 batch tiles per k-step, 256 registers per lane) reduce their slice
-// sums in order through LDS and store the half's fp32 sum to part[half][row][col]; the consumer of the residual stream — always a norm kernel at these
-// batch sizes — adds lo + hi, the fp8 scale and the residual exactly as proj_epilogue does (dec_norm_ximg_kernel<true>).  Every projection kernel adds its
-// 16 slice sums as (s0 + .. + s7) + (s8 + .. + s15) since this round (proj_sum16), so a row's bits do not depend on which kernel ran.
-constexpr int KH_G = 4;              // k-steps per round: KH_G x (NM weight + 4 activation fragments) requested together
+// The projections above 32 rows as FOUR K quarters (round 6).  dec_proj_wide_kernel (decode_fused.hip) gives a workgroup a few output features over the FULL
+// K, so every workgroup reads the WHOLE X image — for down_proj 64 x 8960 x 2 B = 1.15 MB beside its 0.43 MB of weights on the 64-CU partition, beside
+// 143 KB on the whole chip — and a CU pulls ~50 GB/s whatever the source (profiles/r06_decode_trace_b64.txt): the kernel sat on that line.  Here a workgroup
+// owns ONE quarter of K (slices 4q .. 4q + 3 of the same 16 slices, same boundaries) for four times the features: a quarter of the X bytes per workgroup, the
+// same weight bytes.  Its 4 waves — one slice each, ALL features of the workgroup: NM MFMAs of 16 weight rows x 4 batch tiles per k-step, one wave per SIMD
+// and its 512 registers — reduce their slice sums in order through LDS and store the quarter's fp32 sum to part[q][row][col]; the consumer of the residual
+// stream — always a norm kernel at these batch sizes — adds (q0 + q1) + (q2 + q3), the fp8 scale and the residual exactly as proj_epilogue does
+// (dec_norm_ximg_kernel<true>).  Every projection kernel adds its 16 slice sums in that order since this round (proj_sum16), so a row's bits do not depend on
+// which kernel ran.
+constexpr int KS_G = 4;              // k-steps per round: KS_G x (NM weight + 4 activation fragments) requested together
+constexpr int KS_WAVES = 16 / DEC_KSPLIT_PARTS;
 template <int NM, typename WT>
-__global__ __launch_bounds__(512) void dec_proj_khalf_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, float* __restrict__ part,
-                                                             int B, int N, int K, int NU) {
+__global__ __launch_bounds__(KS_WAVES * 64) void dec_proj_ksplit_kernel(const bf16_t* __restrict__ X, const WT* __restrict__ Wd, float* __restrict__ part,
+                                                                        int B, int N, int K, int NU) {
     constexpr int TT = S64_TT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                                  // [8 slices][NM][TT][64]
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                                  // [KS_WAVES slices][NM][TT][64]
     const int lane = threadIdx.x & 63, wv = wave_id();
     const int m = lane & 15, g = lane >> 4;
-    const int half = blockIdx.x, n_tiles = (B + 15) >> 4, n_units = N >> 3;
+    const int quarter = blockIdx.x, n_tiles = (B + 15) >> 4, n_units = N >> 3;
     const int u0 = blockIdx.y * NU;
-    const int KS = K / 32, sl = 8 * half + wv;
+    const int KS = K / 32, sl = KS_WAVES * quarter + wv;
     const int k0 = (int)((uint32_t)(sl * KS) >> 4), k1 = (int)((uint32_t)((sl + 1) * KS) >> 4);       // the 16-slice boundaries of dec_proj_kernel
     uint32_t woff[NM];
 #pragma unroll
@@ -117,11 +122,11 @@ __global__ __launch_bounds__(512) void dec_proj_khalf_kernel(const bf16_t* __res
         for (int j = 0; j < NM; ++j)
 #pragma unroll
             for (int t = 0; t < TT; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
-        for (int kb = k0 + par; kb < k1; kb += 2 * KH_G) {                        // wave-uniform trip count
-            WT a[NM][KH_G];
-            bf16x8 b[TT][KH_G];
+        for (int kb = k0 + par; kb < k1; kb += 2 * KS_G) {                        // wave-uniform trip count
+            WT a[NM][KS_G];
+            bf16x8 b[TT][KS_G];
 #pragma unroll
-            for (int jj = 0; jj < KH_G; ++jj) {
+            for (int jj = 0; jj < KS_G; ++jj) {
                 const int k = kb + 2 * jj;
                 const bool ok = k < k1;                                           // slots past the slice multiply a chunk of zeros
                 const int kc = min(k, KS - 1);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512) void dec_proj_khalf_kernel(const bf16_t* __res
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int jj = 0; jj < KH_G; ++jj)
+            for (int jj = 0; jj < KS_G; ++jj)
 #pragma unroll
                 for (int j = 0; j < NM; ++j) {
                     const bf16x8 wa = as_a(a[j][jj]);
@@ -154,18 +159,18 @@ __global__ __launch_bounds__(512) void dec_proj_khalf_kernel(const bf16_t* __res
     TRACE(1);
     __syncthreads();
     TRACE(2);
-    // accumulator tile e = (MFMA je, batch tile te): wave wv finishes tiles wv, wv + 8
+    // accumulator tile e = (MFMA je, batch tile te): wave wv finishes tiles wv, wv + KS_WAVES, ...
 #pragma unroll
-    for (int i = 0; i < (NM * TT + 7) / 8; ++i) {
-        const int e = wv + 8 * i;
+    for (int i = 0; i < (NM * TT + KS_WAVES - 1) / KS_WAVES; ++i) {
+        const int e = wv + KS_WAVES * i;
         if (e >= NM * TT) break;                                                  // wave-uniform
         const int je = e / TT, te = e % TT;
         const int ul = 2 * je + (g >> 1), unit = u0 + ul, row = 16 * te + m;
         if (ul < NU && unit < n_units && row < B) {
             f32x4 p = {0, 0, 0, 0};
 #pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) p += red[((size_t)((s8 * NM + je) * TT + te)) * 64 + lane];      // this half of proj_sum16
-            *reinterpret_cast<f32x4*>(part + ((size_t)half * MAX_DECODE_ROWS + row) * N + 8 * unit + 4 * (g & 1)) = p;
+            for (int s4 = 0; s4 < KS_WAVES; ++s4) p += red[((size_t)((s4 * NM + je) * TT + te)) * 64 + lane];      // this quarter of proj_sum16
+            *reinterpret_cast<f32x4*>(part + ((size_t)quarter * MAX_DECODE_ROWS + row) * N + 8 * unit + 4 * (g & 1)) = p;
         }
     }
     TRACE(3);
@@ -233,9 +238,8 @@ __global__ __launch_bounds__(NWV * 64) void dec_stream64_kernel(const bf16_t* __
     auto base_of = [&](int tile) { return Wd + (size_t)tile * KS * 64; };
 
     TRACE(0);
-    dma(0, 0);
-    dma(1, 1);
-    int it = item_of(0);
+    dma(0, 0);                                                                    // chunk 0 first, then the ring's first D k-steps, then chunk 1: the first barrier
+    int it = item_of(0);                                                          // waits for 48 KiB of X, not for 96 (whole chip: it opened 6 us into the kernel)
     const WT* fa = it >= 0 ? base_of(tile_a(it)) : zc;
     const WT* fb = it >= 0 ? base_of(tile_b(it)) : zc;
     int stride = it >= 0 ? 64 : 0;
@@ -251,6 +255,16 @@ __global__ __launch_bounds__(NWV * 64) void dec_stream64_kernel(const bf16_t* __
         fa += stride; fb += stride;
     }
     __builtin_amdgcn_sched_barrier(0);
+    dma(1, 1);
+    // Counted wait in front of every chunk barrier.  Loads return in order, so "at most N operations outstanding" means every load but the N youngest is
+    // back: N must not exceed the number of LOADS issued after the last piece of the chunk that is waited for (stores in flight only make the wait longer):
+    //   chunk 0 of round 0: issued first; behind it the 2 D ring loads and chunk 1's PW pieces;
+    //   chunk 1 of round 0: behind it chunk 2's pieces (issued at the first barrier) and the 2 L refills of the first chunk phase  <- the smallest count;
+    //   every later chunk s: issued at the barrier of chunk s - 2; behind it 2 L refills, chunk s + 1's pieces, 2 L refills.
+    // One constant for all of them (no branches in the stream): min(2 D, PW + 2 L) — 2 D, i.e. the whole ring stays in flight, for the 8- and 12-wave plans.
+    // (Round 6 review: with L = 6 and a 24-deep ring the former vmcnt(2 D) allowed MORE operations in flight than had been issued behind chunk s — it did
+    // not wait for the chunk at all; the small-model tests passed on timing.)
+    constexpr int WAIT_N = 2 * D < PW + 2 * L ? 2 * D : PW + 2 * L;
 
     for (int r = 0; r < rounds; ++r) {
         const int it_n = r + 1 < rounds ? item_of(r + 1) : -1;
@@ -268,8 +282,8 @@ __global__ __launch_bounds__(NWV * 64) void dec_stream64_kernel(const bf16_t* __
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int seq = 4 * r + c;
-            // own pieces of chunk seq (and seq + 1) are in: the youngest 2 D operations are ring loads, all younger than those DMAs
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
+            // own pieces of chunk seq are in
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_N) : "memory");
             __builtin_amdgcn_s_barrier();                                         // everybody's pieces of chunk seq are in; everybody is done with chunk seq - 1
             TRACE(1 + c);
             dma((seq + 2) % S64_NBUF, (c + 2) & 3);                               // into the buffer of chunk seq - 1 (past the last chunk: a copy nobody reads)
@@ -441,30 +455,33 @@ hipError_t launch_dec_norm_ximg(hipStream_t s, const bf16_t* h_in, const bf16_t*
     return hipGetLastError();
 }
 
-// down_proj above 32 rows as two K halves: part[2][64][N] <- the halves' slice sums (h is NOT updated: launch_dec_norm_ximg(.., part, wscale) does that).
-bool dec_proj_khalf_supports(int B, int N, int K) {
-    static const bool off = getenv("DOTS_OCR_DEC_KHALF") && atoi(getenv("DOTS_OCR_DEC_KHALF")) == 0;      // A/B switch: dec_proj_wide_kernel over the full K
-    return !off && B > 32 && B <= MAX_DECODE_ROWS && N % 16 == 0 && N <= 512 * NC_MAX && K % 32 == 0 && K / 32 >= 64;      // long K only (o_proj's X image is 192 KB); N: what the norm kernel's rows hold
+// the projections above 32 rows as four K quarters: part[4][64][N] <- the quarters' slice sums (h is NOT updated: launch_dec_norm_ximg(.., part, wscale) does that).
+bool dec_proj_ksplit_supports(int B, int N, int K) {
+    const char* env = getenv("DOTS_OCR_DEC_KSPLIT");                // A/B switch, read per call (tests flip it): 0 = dec_proj_wide_kernel over the full K,
+    const int mode = env ? atoi(env) : 1;                           // 1 = long K only (down_proj), 2 = o_proj too
+    const int min_ks = mode >= 2 ? 16 : 64;
+    return mode > 0 && B > 32 && B <= MAX_DECODE_ROWS && N % 16 == 0 && N <= 512 * NC_MAX && K % 32 == 0 && K / 32 >= min_ks;      // N: what the norm kernel's rows hold
 }
 
-hipError_t launch_dec_proj_khalf(hipStream_t s, const bf16_t* X, const void* Wd, bool fp8, float* part, int B, int N, int K, int cus) {
-    if (!dec_proj_khalf_supports(B, N, K) || !part) return hipErrorInvalidValue;
+hipError_t launch_dec_proj_ksplit(hipStream_t s, const bf16_t* X, const void* Wd, bool fp8, float* part, int B, int N, int K, int cus) {
+    if (!dec_proj_ksplit_supports(B, N, K) || !part) return hipErrorInvalidValue;
     if (cus <= 0) cus = device_cus();
-    static uint32_t attr[6] = {0, 0, 0, 0, 0, 0};
+    static uint32_t attr[12] = {0};
     const int n_units = N / 8;
-    // 2 K halves x ceil(n_units / nu) workgroups in ONE round on the CUs the stream may use; a workgroup takes up to 6 units (3 MFMAs of 16 weight rows)
-    const int nu = std::max(1, std::min(6, (2 * n_units + cus - 1) / cus)), nm = (nu + 1) / 2;
-    const size_t lds = (size_t)8 * nm * S64_TT * 64 * sizeof(f32x4);
-    const dim3 grid(2, (n_units + nu - 1) / nu);
+    // 4 K quarters x ceil(n_units / nu) workgroups in ONE round on the CUs the stream may use; a workgroup takes up to 12 units (6 MFMAs of 16 weight rows)
+    const int nu = std::max(1, std::min(12, (DEC_KSPLIT_PARTS * n_units + cus - 1) / cus)), nm = (nu + 1) / 2;
+    const size_t lds = (size_t)KS_WAVES * nm * S64_TT * 64 * sizeof(f32x4);
+    const dim3 grid(DEC_KSPLIT_PARTS, (n_units + nu - 1) / nu);
     auto go = [&](auto kern, auto wd, uint32_t* done) -> hipError_t {
         hipError_t e = ensure_lds64(kern, lds, done);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, X, wd, part, B, N, K, nu);
+        hipLaunchKernelGGL(kern, grid, dim3(KS_WAVES * 64), lds, s, X, wd, part, B, N, K, nu);
         return hipGetLastError();
     };
-    if (nm == 1) return fp8 ? go(dec_proj_khalf_kernel<1, u32x2>, (const u32x2*)Wd, &attr[0]) : go(dec_proj_khalf_kernel<1, bf16x8>, (const bf16x8*)Wd, &attr[1]);
-    if (nm == 2) return fp8 ? go(dec_proj_khalf_kernel<2, u32x2>, (const u32x2*)Wd, &attr[2]) : go(dec_proj_khalf_kernel<2, bf16x8>, (const bf16x8*)Wd, &attr[3]);
-    return fp8 ? go(dec_proj_khalf_kernel<3, u32x2>, (const u32x2*)Wd, &attr[4]) : go(dec_proj_khalf_kernel<3, bf16x8>, (const bf16x8*)Wd, &attr[5]);
+#define KSPLIT(NMV) if (nm == NMV) return fp8 ? go(dec_proj_ksplit_kernel<NMV, u32x2>, (const u32x2*)Wd, &attr[2 * (NMV - 1)]) : go(dec_proj_ksplit_kernel<NMV, bf16x8>, (const bf16x8*)Wd, &attr[2 * (NMV - 1) + 1])
+    KSPLIT(1); KSPLIT(2); KSPLIT(3); KSPLIT(4); KSPLIT(5);
+    return fp8 ? go(dec_proj_ksplit_kernel<6, u32x2>, (const u32x2*)Wd, &attr[10]) : go(dec_proj_ksplit_kernel<6, bf16x8>, (const bf16x8*)Wd, &attr[11]);
+#undef KSPLIT
 }
 
 // act = silu(gate) * up of rmsnorm(h), B in (32, 64]: norm kernel -> xn (scratch: 64 x H bf16), then the streaming kernel.  cus: CUs the stream may use.

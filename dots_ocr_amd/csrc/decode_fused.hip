@@ -174,16 +174,19 @@ __global__ __launch_bounds__(1024) void dec_qkv_kernel(const bf16_t* __restrict_
     TRACE(6);
 }
 
-// ---- split-K reduction of a projection: the 16 slice sums as TWO halves, each added in slice order from zero, then lo + hi (round 6: until then one
-// chain of 16).  The K-half kernel of decode_b64.hip computes `lo` and `hi` in two different workgroups (each needs only its half of the X image) and the
-// norm kernel that consumes the residual stream adds them — so every projection kernel uses this order: a row's bits must not depend on the kernel that ran.
+// ---- split-K reduction of a projection: the 16 slice sums as FOUR quarters, each added in slice order from zero, then (q0 + q1) + (q2 + q3) (round 6: until
+// then one chain of 16).  The K-split kernel of decode_b64.hip computes the four quarters in four different workgroups (each needs only its quarter of the X
+// image) and the norm kernel that consumes the residual stream adds them — so every projection kernel uses this order: a row's bits must not depend on the
+// kernel that ran.
 DEVI f32x4 proj_sum16(const f32x4* red, int stride) {
-    f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+    f32x4 q[4];
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) lo += red[(size_t)sl * stride];
+    for (int i = 0; i < 4; ++i) {
+        q[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int sl = 8; sl < 16; ++sl) hi += red[(size_t)sl * stride];
-    return lo + hi;
+        for (int sl = 4 * i; sl < 4 * i + 4; ++sl) q[i] += red[(size_t)sl * stride];
+    }
+    return (q[0] + q[1]) + (q[2] + q[3]);
 }
 
 // ---- residual epilogue of one lane of a projection: h[row][col0 .. col0 + 3] = bf16(residual + sum * scale).  One definition for the
@@ -993,7 +996,7 @@ hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, co
                           const float* pend, const float* pend_scale) {
     if (H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     const int full_tiles = part_cus > 0;
-    {   // a pending K-half residual update that the X-image path below will not fuse into its norm launch gets a launch of its own
+    {   // a pending K-split residual update that the X-image path below will not fuse into its norm launch gets a launch of its own
         static const bool ximg_on0 = !(getenv("DOTS_OCR_QKV_XIMG") && atoi(getenv("DOTS_OCR_QKV_XIMG")) == 0);
         if (pend && !(B > 16 && wide_on() && xn && B > 32 && ximg_on0)) {
             HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));
@@ -1055,9 +1058,9 @@ hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const
                            float* part, bool* pending) {
     if (N % 16 || K % 32 || K / 32 < 16 || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     if (pending) *pending = false;
-    if (part && pending && wide_on() && dec_proj_khalf_supports(B, N, K)) {          // round 6: two K halves, the residual update is the consumer's (decode_b64.hip)
+    if (part && pending && wide_on() && dec_proj_ksplit_supports(B, N, K)) {         // round 6: four K quarters, the residual update is the consumer's (decode_b64.hip)
         *pending = true;
-        return launch_dec_proj_khalf(s, X, Wd, wscale != nullptr, part, B, N, K, wide_cus(part_cus));
+        return launch_dec_proj_ksplit(s, X, Wd, wscale != nullptr, part, B, N, K, wide_cus(part_cus));
     }
     const int full_tiles = part_cus > 0;
     if (B > 16 && wide_on()) {
@@ -1187,9 +1190,10 @@ static hipError_t gateup_launch(hipStream_t s, const bf16_t* h, const bf16_t* ln
 }
 
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
-                             int B, int H, int I, float eps, int part_cus, bf16_t* xn) {
+                             int B, int H, int I, float eps, int part_cus, bf16_t* xn, const float* pend, const float* pend_scale) {
     if (I % 32 || H % 128 || H > 512 * NC_MAX || H / 32 < GU_WAVES || H / 32 > GU_G * GU_WAVES || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
-    if (xn && dec_stream64_supports(B, H)) return launch_dec_gateup64(s, h, ln_w, W13d, wscale, act, xn, B, H, I, eps, wide_cus(part_cus));      // round 6: four batch tiles per workgroup
+    if (xn && dec_stream64_supports(B, H)) return launch_dec_gateup64(s, h, ln_w, W13d, wscale, act, xn, B, H, I, eps, wide_cus(part_cus), pend, pend_scale);      // round 6: four batch tiles per workgroup
+    if (pend) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));      // the pending K-split residual update, by a launch of its own
     return wscale ? gateup_launch(s, h, ln_w, (const u32x2*)W13d, wscale, act, B, H, I, eps, part_cus)
                   : gateup_launch(s, h, ln_w, (const bf16x8*)W13d, wscale, act, B, H, I, eps, part_cus);
 }
@@ -1219,7 +1223,7 @@ hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w,
                              int B, int H, int V, float eps, int part_cus, bf16_t* xn, const float* pend, const float* pend_scale) {
     if (V % 16 || H % 32 || H > 512 * NC_MAX || B < 1 || B > MAX_DECODE_ROWS) return hipErrorInvalidValue;
     if (xn && dec_stream64_supports(B, H) && H % (32 * 8) == 0) return launch_dec_lmhead64(s, h, ln_w, Wd, wscale, logits, xn, B, H, V, eps, wide_cus(part_cus), pend, pend_scale);
-    if (pend) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));      // the pending K-half residual update, by a launch of its own
+    if (pend) HIP_CHECK_RET(launch_dec_norm_ximg(s, h, nullptr, nullptr, B, H, eps, pend, pend_scale));      // the pending K-split residual update, by a launch of its own
     return wscale ? lmhead_launch(s, h, ln_w, (const u32x2*)Wd, wscale, logits, B, H, V, eps)
                   : lmhead_launch(s, h, ln_w, (const bf16x8*)Wd, wscale, logits, B, H, V, eps);
 }

@@ -194,7 +194,7 @@ struct DotsEngine {
     uint64_t seed = 0;
     int out_cap = 0;                       // row stride of out_ids for the current generation
     bf16_t *d_h = nullptr, *d_q = nullptr, *d_att = nullptr, *d_act = nullptr, *d_xn = nullptr;      // d_xn: normalised rows of batches above 32 rows (decode_b64.hip)
-    float* d_part_h = nullptr;                     // [2][DOTS_MAX_BATCH][hidden] fp32: the K-half sums of down_proj above 32 rows (decode_b64.hip)
+    float* d_part_h = nullptr;                     // [DEC_KSPLIT_PARTS][DOTS_MAX_BATCH][hidden] fp32: the K-quarter sums of a projection above 32 rows (decode_b64.hip)
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_logits = nullptr;
     // decode launch plan forced on every step (dots_set_decode_plan): 0 = by stream (whole chip / CU partition), 1 = always the partition plan
     int force_part = 0;
@@ -571,7 +571,7 @@ int alloc_workspaces(DotsEngine* e) {
     CK(e->alloc(&e->d_att, (size_t)mb * Nq));
     CK(e->alloc(&e->d_act, (size_t)mb * c.intermediate_size));
     CK(e->alloc(&e->d_xn, (size_t)DOTS_MAX_BATCH * H));
-    CK(e->alloc(&e->d_part_h, (size_t)2 * DOTS_MAX_BATCH * H));
+    CK(e->alloc(&e->d_part_h, (size_t)DEC_KSPLIT_PARTS * DOTS_MAX_BATCH * H));
     CK(e->alloc(&e->d_logits, (size_t)mb * c.vocab_size));
     CK(e->alloc(&e->d_part_o, (size_t)mb * c.num_heads * 64 * 128));
     CK(e->alloc(&e->d_part_ml, (size_t)mb * c.num_heads * 64 * 2));
@@ -1084,7 +1084,7 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
     CK(launch_dec_embed(s, e->cur_tokens, e->embed, e->d_h, B, H));
     if (e->force_part) part = 1;                                                   // dots_set_decode_plan(1): the partition plan on every step (tests, A/B runs)
     static const bool same_layer = getenv("DOTS_OCR_DEBUG_SAME_LAYER") != nullptr;   // experiment: all weight reads hit the Infinity Cache
-    bool pend = false;                              // down_proj of the previous layer left its K-half sums in d_part_h: the next norm launch applies them
+    bool pend = false;                              // down_proj of the previous layer left its K-quarter sums in d_part_h: the next norm launch applies them
     const float* pend_scale = nullptr;
     for (int i = 0; i < c.num_layers; ++i) {
         const LLayer& L = e->ll[same_layer ? 0 : i];
@@ -1093,8 +1093,9 @@ int decode_step_launches(DotsEngine* e, int n_splits, int part = 0) {
                           Hkv, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn, pend ? e->d_part_h : nullptr, pend_scale));
         CK(launch_decode_attn(s, e->d_q, pool_l, e->ctx_len, e->block_table, e->max_pages, e->d_part_o, e->d_part_ml, B, Hq, Hkv, n_splits, scale, part ? e->dec_cus : 0, e->attn_stream));
         CK(launch_decode_attn_combine(s, e->d_part_o, e->d_part_ml, e->ctx_len, e->d_att, B, Hq, Hkv, n_splits));
-        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part ? e->dec_cus : 0));
-        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn));
+        bool pend_o = false;
+        CK(launch_dec_proj(s, e->d_att, L.o_wd, L.o_s, e->d_h, B, H, Nq, part ? e->dec_cus : 0, e->d_part_h, &pend_o));
+        CK(launch_dec_gateup(s, e->d_h, L.ln2, L.w13_wd, L.w13_s, e->d_act, B, H, I, c.rms_norm_eps, part ? e->dec_cus : 0, e->d_xn, pend_o ? e->d_part_h : nullptr, L.o_s));
         CK(launch_dec_proj(s, e->d_act, L.down_wd, L.down_s, e->d_h, B, H, I, part ? e->dec_cus : 0, e->d_part_h, &pend));
         pend_scale = L.down_s;
     }
@@ -2019,9 +2020,9 @@ int dots_op_dec_proj(DotsEngine* e, const void* x, const void* w, void* h_inout,
     RET(op_weight(e, sc, (const bf16_t*)w, N, K, 0, 0, false, fp8, &wd, &wscale));
     bool pend = false;
     float* part = nullptr;
-    CK(sc.get(&part, (size_t)2 * DOTS_MAX_BATCH * N));
+    CK(sc.get(&part, (size_t)DEC_KSPLIT_PARTS * DOTS_MAX_BATCH * N));
     CK(launch_dec_proj(e->stream, xi, wd, wscale, (bf16_t*)h_inout, B, N, K, e->force_part ? e->dec_cus : 0, part, &pend));
-    if (pend) CK(launch_dec_norm_ximg(e->stream, (const bf16_t*)h_inout, nullptr, nullptr, B, N, 0.f, part, wscale));        // the K-half kernel leaves the residual update to its consumer
+    if (pend) CK(launch_dec_norm_ximg(e->stream, (const bf16_t*)h_inout, nullptr, nullptr, B, N, 0.f, part, wscale));        // the K-split kernel leaves the residual update to its consumer
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }

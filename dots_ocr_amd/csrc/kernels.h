@@ -60,20 +60,20 @@ hipError_t launch_dec_embed(hipStream_t s, const int32_t* tokens, const bf16_t* 
 // Wd + wscale: wscale == nullptr -> Wd is the bf16 fragment image (launch_pack_frag*); else Wd is the e4m3 fragment image
 // (launch_pack_frag_fp8) and wscale[row] its fp32 per-output-channel scales (quant.hip).
 // xn: scratch for the normalised rows of batches above 32 rows (MAX_DECODE_ROWS x H bf16; decode_b64.hip) or nullptr = the round-4 two-tile kernels.
-// pend / pend_scale (qkv, lm_head): the K-half sums a preceding launch_dec_proj left in `part` instead of updating h (+ that projection's fp8 weight scales or
+// pend / pend_scale (qkv, gate|up, lm_head): the K-quarter sums a preceding launch_dec_proj left in `part` instead of updating h (+ that projection's fp8 weight scales or
 // nullptr): the residual update is applied first — fused into the norm kernel on the xn path, by a launch of its own otherwise.
 hipError_t launch_dec_qkv(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, const bf16_t* bias,
                           const float* inv_freq, const int32_t* ctx_len, const int32_t* block_table, int max_pages,
                           bf16_t* pool_layer, bf16_t* q_out, int B, int H, int Hq, int Hkv, float eps, int part_cus = 0, bf16_t* xn = nullptr,
                           const float* pend = nullptr, const float* pend_scale = nullptr);
-// h += X @ W^T.  part != nullptr (MAX 2 x MAX_DECODE_ROWS x N fp32) allows the K-half kernel above 32 rows and long K: *pending is then set and h is NOT
-// updated by this launch — pass `part` (and wscale) as pend / pend_scale to the next launch_dec_qkv / launch_dec_lmhead, or call launch_dec_norm_ximg(.., part, ..)
+// h += X @ W^T.  part != nullptr (DEC_KSPLIT_PARTS x DOTS_MAX_BATCH x N fp32) allows the K-split kernel above 32 rows: *pending is then set and h is NOT
+// updated by this launch — pass `part` (and wscale) as pend / pend_scale to the next launch_dec_qkv / launch_dec_gateup / launch_dec_lmhead, or call launch_dec_norm_ximg(.., part, ..)
 hipError_t launch_dec_proj(hipStream_t s, const bf16_t* X, const void* Wd, const float* wscale, bf16_t* h, int B, int N, int K, int part_cus = 0,
                            float* part = nullptr, bool* pending = nullptr);
 // part_cus > 0 (all dense launchers): the stream is CU-masked to that many CUs.  qkv / proj: whole 16-row weight tiles per workgroup at B <= 16,
 // one round of wide workgroups above; gate|up: the grid is capped at what the CUs hold at once, the workgroups walk the (gate, up) tile pairs
 hipError_t launch_dec_gateup(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* W13d, const float* wscale, bf16_t* act,
-                             int B, int H, int I, float eps, int part_cus = 0, bf16_t* xn = nullptr);
+                             int B, int H, int I, float eps, int part_cus = 0, bf16_t* xn = nullptr, const float* pend = nullptr, const float* pend_scale = nullptr);
 hipError_t launch_dec_lmhead(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits,
                              int B, int H, int V, float eps, int part_cus = 0, bf16_t* xn = nullptr, const float* pend = nullptr, const float* pend_scale = nullptr);
 // ---- decode_b64.hip (round 6): batches above 32 rows — all four 16-row batch tiles in one workgroup, every weight byte crosses a CU once
@@ -84,8 +84,9 @@ hipError_t launch_dec_gateup64(hipStream_t s, const bf16_t* h, const bf16_t* ln_
                                int B, int H, int I, float eps, int cus, const float* pend = nullptr, const float* pend_scale = nullptr);
 hipError_t launch_dec_lmhead64(hipStream_t s, const bf16_t* h, const bf16_t* ln_w, const void* Wd, const float* wscale, float* logits, bf16_t* xn,
                                int B, int H, int V, float eps, int cus, const float* pend = nullptr, const float* pend_scale = nullptr);
-bool dec_proj_khalf_supports(int B, int N, int K);
-hipError_t launch_dec_proj_khalf(hipStream_t s, const bf16_t* X, const void* Wd, bool fp8, float* part, int B, int N, int K, int cus);
+constexpr int DEC_KSPLIT_PARTS = 4;          // K quarters of the K-split projection; part buffers hold DEC_KSPLIT_PARTS x DOTS_MAX_BATCH x N fp32
+bool dec_proj_ksplit_supports(int B, int N, int K);
+hipError_t launch_dec_proj_ksplit(hipStream_t s, const bf16_t* X, const void* Wd, bool fp8, float* part, int B, int N, int K, int cus);
 int decode_attn_waves();                       // pages in flight per decode-attention workgroup (engine constant)
 int decode_attn_splits(int max_seq_len);       // KV splits for a context capacity: ceil(pages / waves), at most 64
 hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool_layer, const int32_t* ctx_len,

@@ -353,11 +353,14 @@ def test_four_tile_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8, cus, 
         close(logits, ref, rel=1e-4, abs_=1e-3, what="logits of the four-tile lm_head")
 
 
-@pytest.mark.parametrize("cus", [None, 100, 64, 48])       # CUs the launcher plans for: whole chip (1 unit / 1 tile per workgroup), 2 units, 3 units / 2 tiles, 4 units
-@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("cus", [None, 100, 64, 48, 128, 77, 400])     # CUs the launcher plans for: whole chip (1 unit / 1 tile per workgroup), 2 units, 3 units / 2 tiles, 4 units;
+@pytest.mark.parametrize("fp8", [False, True])                          # K-split projections (round 6, above 32 rows): 3 / 8 / 12 / 12 / 6 / 10 / 2 units = 2 / 4 / 6 / 6 / 3 / 5 / 1 MFMAs per k-step
 @pytest.mark.parametrize("B", [17, 33, 40, 64])
 def test_wide_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8, cus, monkeypatch):
-    """Round 5: above 16 rows dec_qkv and the two projections run the WIDE kernels (all batch tiles in one workgroup, no LDS X image, parity
+    """Round 6 addition: above 32 rows the projections run as FOUR K quarters (dec_proj_ksplit_kernel, decode_b64.hip: a quarter of the X image per workgroup,
+    the quarters' fp32 sums added by the consumer's norm kernel — here by the single-kernel entry point's residual-update launch) — the same bitwise contract,
+    for every number of MFMAs per k-step the launcher can choose.
+    Round 5: above 16 rows dec_qkv and the two projections run the WIDE kernels (all batch tiles in one workgroup, no LDS X image, parity
     passes over the K slices; csrc/decode_fused.hip).  Per output element their arithmetic is the per-tile kernels': the rows of a B-row
     call equal, bit for bit, the same rows computed in calls of at most 16 rows — q, the appended K / V page slots, and both residual
     projections (o_proj K = 1536, down_proj K = 8960) — for every workgroup shape the launcher can choose (DOTS_OCR_DEC_WIDE_CUS)."""
@@ -365,6 +368,7 @@ def test_wide_kernels_equal_the_one_tile_kernels_bitwise(eng, B, fp8, cus, monke
         monkeypatch.delenv("DOTS_OCR_DEC_WIDE_CUS", raising=False)
     else:
         monkeypatch.setenv("DOTS_OCR_DEC_WIDE_CUS", str(cus))
+    monkeypatch.setenv("DOTS_OCR_DEC_KSPLIT", "2")          # both projections through the K-split kernel above 32 rows (the default splits down_proj only)
     g = torch.Generator().manual_seed(B * 7 + 5)
     h = bf(torch.randn(B, H, generator=g) * 2)
     ln_w = bf(1 + 0.1 * torch.randn(H, generator=g))

@@ -142,17 +142,18 @@ int main(int argc, char** argv) {
     // stay distinct — the UPPER BOUND of any scheme that prefetches the small kernels' weights into L2 ahead of their launch (VERDICT r5 #2b)
     if (getenv("DOTS_BENCH_SHARE_SMALL")) { for (int i = 1; i < L; ++i) { qkv[i] = qkv[0]; o[i] = o[0]; } printf("qkv / o_proj weights shared by all layers (L2-resident)\n"); }
     if (getenv("DOTS_BENCH_SHARE_ALL")) { for (int i = 1; i < L; ++i) { qkv[i] = qkv[0]; o[i] = o[0]; w13[i] = w13[0]; down[i] = down[0]; } printf("all layer weights shared (Infinity-Cache-resident)\n"); }
-    float* part_h = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<float>((size_t)2 * 64 * H);      // K-half sums of down_proj above 32 rows (decode_b64.hip)
+    float* part_h = getenv("DOTS_BENCH_NO_XN") ? nullptr : dalloc<float>((size_t)DEC_KSPLIT_PARTS * 64 * H);      // K-quarter sums of the projections above 32 rows (decode_b64.hip)
     // (the pending residual update of the previous layer's K-half down_proj rides in this layer's norm launch, as in engine.hip)
     auto k_qkv = [&](int i) { CK(launch_dec_qkv(S, h0, ln1[i], qkv[i], wsc, bias[i], inv_freq, ctx_len, tab, max_pages, pool + pool_layer * i, dq, B, H, Hq, Hkv, eps, part_cus, xn,
-                                                 part_h && dec_proj_khalf_supports(B, H, I) ? part_h : nullptr, wsc)); };
+                                                 part_h && dec_proj_ksplit_supports(B, H, I) ? part_h : nullptr, wsc)); };
     auto k_attn = [&](int i) { CK(launch_decode_attn(S, dq, pool + pool_layer * i, ctx_len, tab, max_pages, po, pml, B, Hq, Hkv, n_splits, scale, part_cus)); };
     auto k_comb = [&](int) { CK(launch_decode_attn_combine(S, po, pml, ctx_len, att, B, Hq, Hkv, n_splits)); };
-    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, part_cus)); };
-    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus, xn)); };
+    bool pend_o = false;
+    auto k_o = [&](int i) { CK(launch_dec_proj(S, att, o[i], wsc, h0, B, H, Nq, part_cus, part_h, &pend_o)); };
+    auto k_gu = [&](int i) { CK(launch_dec_gateup(S, h0, ln2[i], w13[i], wsc, act, B, H, I, eps, part_cus, xn, part_h && dec_proj_ksplit_supports(B, H, Nq) ? part_h : nullptr, wsc)); };
     bool pend = false;
     auto k_down = [&](int i) { CK(launch_dec_proj(S, act, down[i], wsc, h0, B, H, I, part_cus, part_h, &pend)); };
-    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps, part_cus, xn, part_h && dec_proj_khalf_supports(B, H, I) ? part_h : nullptr, wsc)); };
+    auto k_lm = [&]() { CK(launch_dec_lmhead(S, h0, fnorm, lm, wsc, logits, B, H, V, eps, part_cus, xn, part_h && dec_proj_ksplit_supports(B, H, I) ? part_h : nullptr, wsc)); };
     // skip: bit mask of kernel kinds left out (marginal cost of a kind inside the real, HBM-cold step = full - skipped)
     auto step_skip = [&](int skip) {
         CK(launch_dec_embed(S, cur, embed, h0, B, H));
