@@ -1980,8 +1980,10 @@ int dots_op_dec_qkv(DotsEngine* e, const void* h, const void* ln_w, const void* 
     for (int i = 0; i < 64; ++i) f[i] = 1.0f / powf(rope_theta, (float)(2 * i) / 128.0f);
     CK(hipMemcpyAsync(freq, f, sizeof(f), hipMemcpyHostToDevice, e->stream));
     RET(op_weight(e, sc, (const bf16_t*)wqkv, (int64_t)(Hq + 2 * Hkv) * 128, H, Hq, Hkv, true, fp8, &wd, &wscale));
+    bf16_t* xn = nullptr;                            // scratch sized for THIS call's hidden size (the engine's own d_xn is sized for its model: the tests run the
+    CK(sc.get(&xn, (size_t)DOTS_MAX_BATCH * H));     // BASELINE dimensions through a small-model engine)
     CK(launch_dec_qkv(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (const bf16_t*)bias, freq, ctx_len_dev, block_table_dev, max_pages,
-                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps, e->force_part ? e->dec_cus : 0, e->d_xn));      // dots_set_decode_plan(1): the partition plan's kernels
+                      (bf16_t*)pool_layer, (bf16_t*)q_out, B, H, Hq, Hkv, eps, e->force_part ? e->dec_cus : 0, xn));      // dots_set_decode_plan(1): the partition plan's kernels
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
@@ -2039,7 +2041,9 @@ int dots_op_dec_gateup(DotsEngine* e, const void* h, const void* ln_w, const voi
     CK(sc.get(&act, (size_t)(B + 15) / 16 * 16 * I));
     CK(launch_pack_w13(e->stream, (const bf16_t*)gate_w, (const bf16_t*)up_w, w13, I, H));
     RET(op_weight(e, sc, w13, (int64_t)2 * I, H, 0, 0, false, fp8, &w13d, &wscale));
-    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps, e->force_part ? e->dec_cus : 0, e->d_xn));
+    bf16_t* xn = nullptr;
+    CK(sc.get(&xn, (size_t)DOTS_MAX_BATCH * H));
+    CK(launch_dec_gateup(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, w13d, wscale, act, B, H, I, eps, e->force_part ? e->dec_cus : 0, xn));
     CK(launch_unpack_x(e->stream, act, (bf16_t*)act_out, B, I));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
@@ -2052,7 +2056,9 @@ int dots_op_dec_lmhead(DotsEngine* e, const void* h, const void* ln_w, const voi
     void* wd = nullptr;
     float* wscale = nullptr;
     RET(op_weight(e, sc, (const bf16_t*)w, V, H, 0, 0, false, fp8, &wd, &wscale));
-    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (float*)logits_out, B, H, V, eps, e->force_part ? e->dec_cus : 0, e->d_xn));
+    bf16_t* xn = nullptr;
+    CK(sc.get(&xn, (size_t)DOTS_MAX_BATCH * H));
+    CK(launch_dec_lmhead(e->stream, (const bf16_t*)h, (const bf16_t*)ln_w, wd, wscale, (float*)logits_out, B, H, V, eps, e->force_part ? e->dec_cus : 0, xn));
     CK(hipStreamSynchronize(e->stream));
     return DOTS_OK;
 }
