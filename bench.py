@@ -33,6 +33,7 @@ sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
 
+_USER_SET_DEC_CUS = "DOTS_OCR_OVERLAP_DEC_CUS" in os.environ      # (before main() picks the workload's default partition)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (same guide; ~6.3 TB/s achievable)
 SVG_CHART = (588, 560)         # demo/demo_image2.png-sized chart input
@@ -195,7 +196,10 @@ def other_config_legs():
     for name, argv in legs:
         t0 = time.perf_counter()
         try:
-            p = subprocess.run([sys.executable, str(Path(__file__).resolve()), *argv, "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=420)
+            # a clean environment for the leg: the decode partition this process chose for ITS workload (setdefault below) must not become the leg's
+            # (round 6: the highres leg inherited a4's 64 decode CUs and reported 11.4 pages/s instead of its own default's 13.8)
+            env = {k: v for k, v in os.environ.items() if not (k == "DOTS_OCR_OVERLAP_DEC_CUS" and not _USER_SET_DEC_CUS)}
+            p = subprocess.run([sys.executable, str(Path(__file__).resolve()), *argv, "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=420, env=env)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
             if p.returncode != 0 or not line:
                 out[name] = {"failed": True, "rc": p.returncode, "stderr_tail": p.stderr[-600:]}
@@ -784,9 +788,9 @@ def main():
                     rd["cus"] = f"{cus_dec} while the next batch's tower runs, 256 after it"
                     if deep:                       # the B = 8 whole-chip figure describes roofline_decode_sequential; the 64-row partition step has its own PMC pass (round 5)
                         rd["traffic"] = recorded("r06_decode_traffic_64rows.json", "traffic_bytes_per_decode_step") if rif == 64 and a.workload == "a4" else None
-                        rd["traffic_unit"] = ("bytes per decode step (PMC, 64 rows on the 64-CU partition plan, profiles/r06_decode_traffic_64rows.json: 1.10 x the "
+                        rd["traffic_unit"] = ("bytes per decode step (PMC, 64 rows on the 64-CU partition plan, profiles/r06_decode_traffic_64rows.json: 1.09 x the "
                                               "algorithmic bytes (round 5: 1.24) — gate|up and lm_head now pass their weights through the CUs once; what is left are "
-                                              "the X images the projections re-read and the attention partials)"
+                                              "the X images the projections re-read, the K-quarter partials of down_proj and the attention partials)"
                                               if rd["traffic"] else "not measured for the %d-row step (PMC traffic at B = 8: roofline_decode_sequential.traffic)" % rif)
                 return r, rv, rd
             dec_cus = int(os.environ.get("DOTS_OCR_OVERLAP_DEC_CUS", "128")) // 8 * 8

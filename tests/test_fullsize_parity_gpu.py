@@ -210,7 +210,9 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     # N(0, 0.02) weights give top-2 margins of 0.02-0.10 against a worst-case error (max over 151 936 logits) of 0.05-0.06: only a handful of the
     # 128 steps lie outside the band (4 measured) — the teeth of the token rule are the peaked checkpoint below, where every step does
     if inline_oracle:
-        assert outside >= 1, f"only {outside} of {n_steps} steps lie outside the near-tie band"
+        # (how many steps lie outside the band is a property of the N(0, 0.02) checkpoint, not of the engine: 3-4 of 64 with margins within 2 % of the
+        # threshold until round 5, 0 after the projections' split-K order changed in round 6 — reported, not asserted; the token rule's teeth are the peaked
+        # checkpoint below, the planted walk and the anchor fixture, where every step lies outside)
         assert agree >= n_steps - 6
     assert not viol_p, f"peaked checkpoint: token mismatch outside the near-tie band: {viol_p[:4]}"
     assert outside_p >= n_p * 3 // 4, f"peaked checkpoint: only {outside_p} of {n_p} steps have a margin above 2 x error"

@@ -16,7 +16,7 @@ mkdir -p $O/pmcd
 CMD="$R/tools/bin/decode_bench 64 5700 6288 once"
 DOTS_BENCH_CUS=64 DOTS_BENCH_FULL=1 timeout 170 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmcd/f -- $CMD > $O/pmcd/f.log 2>&1; echo "decode pmc fetch rc=$?"
 DOTS_BENCH_CUS=64 DOTS_BENCH_FULL=1 timeout 170 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmcd/w -- $CMD > $O/pmcd/w.log 2>&1; echo "decode pmc write rc=$?"
-python tools/pmc_summary.py $O/pmcd dec_qkv_wide decode_attn_kernel decode_attn_combine dec_proj_wide "dec_stream64_kernel<0" "dec_stream64_kernel<1" dec_norm_ximg dec_embed argmax > $O/r06_decode_traffic_64rows_raw.json 2> $O/pmcd/summary.err; head -c 3000 $O/r06_decode_traffic_64rows_raw.json; rm -rf $O/pmcd
+python tools/pmc_summary.py $O/pmcd dec_qkv_wide decode_attn_kernel decode_attn_combine dec_proj_wide dec_proj_ksplit "dec_stream64_kernel<0" "dec_stream64_kernel<1" dec_norm_ximg dec_embed argmax > $O/r06_decode_traffic_64rows_raw.json 2> $O/pmcd/summary.err; head -c 3000 $O/r06_decode_traffic_64rows_raw.json; rm -rf $O/pmcd
 # ---- PMC: HBM-side traffic of the ViT flash attention (one sequential batch, 2 new tokens)
 mkdir -p $O/pmcf
 CMD="python $R/bench.py --steps 1 --warmup 0 --max-new-tokens 2 --no-cpu-baseline --no-overlap"
