@@ -377,9 +377,18 @@ constexpr int RING_BYTES = RING * 2 * KT_BYTES;               // KT_BYTES == VT_
 #define F64_EXP_A ""
 #define F64_EXP_B ""
 #define F64_EXP_C ""
+#define F64_C_EXTRA
+#elif defined(F64_DOT2)
+// -DF64_DOT2 (EXPERIMENT): the row sums are taken from the ROUNDED P words, one v_dot2c_f32_bf16 (ps += p.lo * 1 + p.hi * 1) per pair instead of two
+// v_add_f32: 12 fillers per three gaps = the measured 4 free slots per MFMA.  l is then the sum of exactly the bf16 values the product MFMAs see.
+#define F64_EXP_A "v_fma_f32 %[t0], %[x0], %[sc], -%[m]\n\tv_fma_f32 %[t1], %[x1], %[sc], -%[m]\n\tv_exp_f32_e32 %[t0], %[t0]\n\tv_exp_f32_e32 %[t1], %[t1]"
+#define F64_EXP_B "v_cvt_pk_bf16_f32 %[wx], %[t0], %[t1]\n\tv_fma_f32 %[u0], %[y0], %[sc], -%[m]\n\tv_fma_f32 %[u1], %[y1], %[sc], -%[m]\n\tv_exp_f32_e32 %[u0], %[u0]"
+#define F64_C_EXTRA , [wxi] "v"(pw[xb][xsl][xe]), [one2] "s"(0x3F803F80u)
+#define F64_EXP_C "v_exp_f32_e32 %[u1], %[u1]\n\tv_dot2c_f32_bf16_e32 %[ps], %[one2], %[wxi]\n\tv_cvt_pk_bf16_f32 %[wy], %[u0], %[u1]\n\tv_dot2c_f32_bf16_e32 %[ps], %[one2], %[wy]"
 #else
 #define F64_EXP_A "v_fma_f32 %[t0], %[x0], %[sc], -%[m]\n\tv_fma_f32 %[t1], %[x1], %[sc], -%[m]\n\tv_exp_f32_e32 %[t0], %[t0]\n\tv_exp_f32_e32 %[t1], %[t1]\n\tv_add_f32_e32 %[ps], %[ps], %[t0]"
 #define F64_EXP_B "v_add_f32_e32 %[ps], %[ps], %[t1]\n\tv_cvt_pk_bf16_f32 %[wx], %[t0], %[t1]\n\tv_fma_f32 %[u0], %[y0], %[sc], -%[m]\n\tv_fma_f32 %[u1], %[y1], %[sc], -%[m]\n\tv_exp_f32_e32 %[u0], %[u0]"
+#define F64_C_EXTRA
 #define F64_EXP_C "v_exp_f32_e32 %[u1], %[u1]\n\tv_add_f32_e32 %[ps], %[ps], %[u0]\n\tv_add_f32_e32 %[ps], %[ps], %[u1]\n\tv_cvt_pk_bf16_f32 %[wy], %[u0], %[u1]"
 #endif
 
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                                      : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [m] "v"(m_run[yb]));
                     else
                         asm volatile(F64_MFMA_S F64_EXP_C : [d] "+v"(sn[bk][hf]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
-                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [u0] "v"(u0));
+                                     : [a] "v"(fa[cur][hf]), [b] "a"(qf[bk][ks]), [u0] "v"(u0) F64_C_EXTRA);
                 } else {
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[bk][sl][0], pw[bk][sl][1], pw[bk][sl][2], pw[bk][sl][3]});
                     if constexpr (ph == 0)
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(
                                      : [a] "v"(fa[cur][hf]), [b] "v"(pf), [t0] "v"(t0), [t1] "v"(t1), [y0] "v"(ys0), [y1] "v"(ys1), [sc] "s"(scale_log2e), [m] "v"(m_run[yb]));
                     else
                         asm volatile(F64_MFMA_S F64_EXP_C : [d] "+a"(o[bk][dt]), [ps] "+v"(ps[yb]), [wy] "=&v"(pw[yb][ysl][ye]), [u1] "+v"(u1)
-                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [u0] "v"(u0));
+                                     : [a] "v"(fa[cur][hf]), [b] "v"(pf), [u0] "v"(u0) F64_C_EXTRA);
                 }
             }
         });

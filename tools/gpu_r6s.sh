@@ -1,0 +1,11 @@
+# Round 6, GPU call S: flash_attn64_kernel with row sums by v_dot2c_f32_bf16 (-DF64_DOT2): parity tests on the variant, same-box A/B
+cd /tmp && export TMPDIR=/tmp; ulimit -c 0
+R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/r6s; mkdir -p $O; rm -f $O/ab.txt
+V=$R/tools/bin/var_dot2/libdots_ocr_hip.so
+( DOTS_OCR_LIB=$V timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "flash or attn" ) > $O/pytest_variant.log 2>&1; echo "variant kernel tests rc=$?"; tail -2 $O/pytest_variant.log
+for rep in 1 2; do for v in base dot2; do
+  if [ $v = base ]; then L=""; else L="DOTS_OCR_LIB=$V"; fi
+  ( env $L timeout 200 python tools/microbench.py flash --seqs 8 --iters 6 ) 2>&1 | grep "flash attn" | sed "s/^/$v: /" >> $O/ab.txt
+done; done
+cat $O/ab.txt
+( DOTS_OCR_LIB=$V timeout 900 python -m pytest tests/test_fullsize_vit_parity_gpu.py tests/test_a4_anchor_gpu.py -x -q -m gpu ) > $O/pytest_variant2.log 2>&1; echo "variant tower parity rc=$?"; tail -2 $O/pytest_variant2.log
