@@ -190,7 +190,7 @@ def other_config_legs():
     legs = [("highres", ["--workload", "highres", "--batch", "4", "--steps", "8", "--warmup", "4"]),      # configs[2]: batch = 4      # (the adaptive tower tail settles within the warm-up steps: 3 / 1 measured 11.1 pages/s against 14.4 at 5 / 2)
             ("mixed64", ["--workload", "mixed64", "--steps", "1", "--warmup", "0"]),
             ("svg_fp8", ["--workload", "svg", "--steps", "1", "--warmup", "1"])]
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "output_tok_s", "roofline", "roofline_decode", "roofline_decode_sequential",
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "output_tok_s", "roofline", "roofline_decode", "roofline_decode_sequential", "roofline_decode_alone_rows_in_flight",
             "parity_vs_sequential", "steps_checked", "page_sets", "parity_vs_single_sequence", "pages_checked", "phase_ms_per_step", "h2d", "setup_s")
     out = {}
     for name, argv in legs:
@@ -484,7 +484,7 @@ def main():
         eng.vit_forward, eng.vit_prefetch, eng.slots_decode, eng.slots_poll = vit_forward_m, vit_prefetch_m, slots_decode_m, slots_poll_m
         mixed_meter["harvest"] = harvest
 
-    deep_state = {"k": 0, "queue": [], "last_decode_ms": 0.0}
+    deep_state = {"k": 0, "queue": [], "last_decode_ms": 0.0, "plen": {}}
     tower_after_prefill = os.environ.get("DOTS_BENCH_TOWER_NOW") != "1"      # =1: the next tower starts beside this batch's prefill (A/B; measured slower)
     trace_steps = os.environ.get("DOTS_BENCH_TRACE") == "1"      # host-side timeline of every pipelined step on stderr
     half_steps = -(-a.max_new_tokens // n_groups)    # decode steps per timed step: a batch gets n_groups x half_steps >= max_new_tokens - 1 of them
@@ -511,6 +511,8 @@ def main():
         if tr: tr.append(("preprocess+prefetch", time.perf_counter()))
         group = [(k % n_groups) * B + i for i in range(B)]
         eng.slots_prefill(group, np.concatenate(prompts), [len(p) for p in prompts], [a.max_new_tokens] * B)
+        for s_, p_ in zip(group, prompts):
+            deep_state["plen"][s_] = len(p_)
         if tr: tr.append(("slots_prefill", time.perf_counter()))
         eng.slots_poll()                             # the prefill is done (synchronises with the main stream's chain only, not with the tower):
         td = time.perf_counter()                     # the decode chunks are timed from here
@@ -626,6 +628,34 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
+    # ---- the decode step the timed region replays, ALONE on the chip (outside the timed region, rank 0): one more batch is admitted with no
+    # look-ahead tower behind it, so every slot group holds rows; 64 graph replays on the whole chip, host-synchronised on both sides
+    dec_alone_rows = None
+    if deep and not sliced and not mixed and rank == 0 and os.environ.get("DOTS_BENCH_DECODE_ALONE", "1") != "0":
+        k_ = deep_state["k"]
+        eng.vit_take()
+        prompts_ = prompts_of(k_ % n_sets)
+        group_ = [(k_ % n_groups) * B + i for i in range(B)]
+        eng.slots_prefill(group_, np.concatenate(prompts_), [len(p_) for p_ in prompts_], [a.max_new_tokens] * B)
+        for s_, p_ in zip(group_, prompts_):
+            deep_state["plen"][s_] = len(p_)
+        fin_, lens_ = eng.slots_poll()
+        eng.synchronize(); torch.cuda.synchronize()      # nothing else is queued: no tower, no prefill
+        live_ = [s_ for s_ in range(len(fin_)) if fin_[s_] == 0]
+        n_alone = 64
+        assert all(lens_[s_] + n_alone < a.max_new_tokens for s_ in live_), "a row would finish inside the decode-alone measurement"
+        ta = time.perf_counter()
+        eng.slots_decode(n_alone)
+        eng.slots_poll()
+        ms_alone = (time.perf_counter() - ta) * 1e3 / n_alone
+        kv_tok_ = cfg.num_hidden_layers * cfg.num_key_value_heads * 128 * 2 * 2
+        ctx0 = [deep_state["plen"][s_] + int(lens_[s_]) for s_ in live_]       # tokens in the KV cache of each row before the first of the n_alone steps
+        bytes_alone = W + kv_tok_ * sum(c_ + (n_alone - 1) / 2.0 + 1 for c_ in ctx0)     # mean over the steps: every weight byte once + the KV read
+        dec_alone_rows = {"bound": "hbm", "achieved": bytes_alone / (ms_alone * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "rows": len(live_),
+                          "ms_per_step": ms_alone, "steps": n_alone, "mean_context": float(np.mean(ctx0)) + n_alone / 2.0, "algorithmic_bytes_per_step": bytes_alone,
+                          "cus": 256, "note": "the decode step of the timed region (every slot group holding rows) replayed alone on the whole chip after the timed region: "
+                                              "no tower, no prefill; wall time of %d hipGraph replays, host-synchronised on both sides" % n_alone}
+        dec_alone_rows["frac"] = dec_alone_rows["achieved"] / dec_alone_rows["peak"]
     # ---- parity of what was timed: every pipelined step (CU-masked side stream, half-chip decode plan, deferred tower)
     # decoded the same pages with the same prompts as the strictly sequential batch this run started with — the tokens must be
     # identical bit for bit, on every rank, or the run fails.
@@ -856,6 +886,12 @@ def main():
                               "step_hbm_frac": last["decode_bytes"] / step_s / 1e9 / PEAK_HBM_GBS,
                               "north_star": {"vit_mfma_frac": 0.40, "decode_hbm_frac": 0.50},
                               "met": {"vit_mfma": bool(vit_alone >= 0.40), "decode_hbm": bool(dec_alone >= 0.50)}}
+            if dec_alone_rows is not None:          # the timed region's own decode step (all slot groups full) alone on the chip, measured after the timed region
+                res["roofline_decode_alone_rows_in_flight"] = dec_alone_rows
+                res["targets"]["decode_hbm_frac_alone_rows_in_flight"] = dec_alone_rows["frac"]
+                res["targets"]["decode_hbm_basis"] = ("decode_hbm_frac_alone / met.decode_hbm: B = %d (the sequential batch); decode_hbm_frac_alone_rows_in_flight: the "
+                                                      "%d-row step the timed region replays, alone on the chip" % (B, dec_alone_rows["rows"]))
+                res["targets"]["met"]["decode_hbm_rows_in_flight"] = bool(dec_alone_rows["frac"] >= 0.50)
             if a.workload == "svg":                 # 4096 decode steps at B = 1 dominate this configuration: its roofline is the HBM one
                 res["roofline_vit_attn"] = res["roofline"]
                 res["roofline"] = {**res["roofline_decode"], "kernel": "one decode step (dec_qkv / decode_attn / combine / dec_proj / dec_gateup x 28 + dec_lmhead)"}
