@@ -85,8 +85,9 @@ def test_a4_decode_parity_pipelined_equals_sequential_and_peaked_checkpoint():
     # time).  The fp32-oracle tolerance (max |logit err| <= 0.125) at this context length is asserted by tests/test_a4_anchor_gpu.py against a
     # committed full-depth oracle run — the oracle's OWN tower included — with no oracle time in the suite.
     n_steps, n_f32 = 64, 0
-    # ... and once that fixture holds 64 teacher-forced steps (tools/make_a4_anchor.py, N_STEPS = 64) the emulated pass below — 100 s of LM prefill + decode on
-    # the host for an LM-only comparison — is redundant too: the anchor test then holds the same 64 steps of the WHOLE path to the same token rule.  What
+    # ... and as that fixture holds 64 teacher-forced steps (tools/make_a4_anchor.py, N_STEPS = 64) the emulated pass below — 100 s of LM prefill + decode on
+    # the host for an LM-only comparison — is redundant too (it only runs if the fixture is ever regenerated shorter): the anchor test holds the same 64 steps
+    # of the WHOLE path to the same token rule.  What
     # stays here is everything only the GPU can say: step-by-step == graph replay, pipelined == sequential bit for bit, the peaked checkpoint.
     try:
         anchor_steps = int(np.load(ROOT / "tests" / "golden" / "a4_anchor.npz")["tokens_emu"].shape[0])
