@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void convert_x_kernel(const bf16_t* __restrict
 constexpr int AT_LD = 132;
 
 template <int NW, bool ONE>
-__global__ __launch_bounds__(NW * 64, ONE ? 3 : 2) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
+__global__ __launch_bounds__(NW * 64, ONE && NW <= 4 ? 3 : 2) void decode_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pool,
                                                           const int32_t* __restrict__ ctx_len, const int32_t* __restrict__ block_table,
                                                           int max_pages, float* __restrict__ part_o, float* __restrict__ part_ml,
                                                           int Hq, int Hkv, int n_splits, float scale_log2e) {
@@ -703,11 +703,13 @@ hipError_t launch_unpack_x(hipStream_t s, const bf16_t* x, bf16_t* dst, int rows
 
 // Waves (= pages in flight) per decode-attention workgroup and with it the KV split: an ENGINE constant, never a function of the
 // batch (a sequence's partial sums must depend on its own context only).  DOTS_OCR_ATTN_WAVES overrides it for experiments.
+// Measured round 6 (profiles/r06_decode_attn_waves_ab.txt): 1 and 2 waves are slower everywhere; 8 waves gain 1.5 % of the step at 8 rows, lose 6 % at one
+// row (svg) and 1.4 % at 64 rows on the 64-CU partition: 4 stays.
 int decode_attn_waves() {
     static const int nw = [] {
         const char* e = getenv("DOTS_OCR_ATTN_WAVES");
         const int v = e ? atoi(e) : 4;
-        return (v == 1 || v == 2) ? v : 4;
+        return (v == 1 || v == 2 || v == 8) ? v : 4;
     }();
     return nw;
 }
@@ -768,6 +770,7 @@ hipError_t launch_decode_attn(hipStream_t s, const bf16_t* q, const bf16_t* pool
     switch (nw) {
         case 1: if (one) ATTN_GO(1, true); else ATTN_GO(1, false); break;
         case 2: if (one) ATTN_GO(2, true); else ATTN_GO(2, false); break;
+        case 8: if (one) ATTN_GO(8, true); else ATTN_GO(8, false); break;
         default: if (one) ATTN_GO(4, true); else ATTN_GO(4, false); break;
     }
 #undef ATTN_GO
