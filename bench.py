@@ -632,30 +632,36 @@ def main():
     # look-ahead tower behind it, so every slot group holds rows; 64 graph replays on the whole chip, host-synchronised on both sides
     dec_alone_rows = None
     if deep and not sliced and not mixed and rank == 0 and os.environ.get("DOTS_BENCH_DECODE_ALONE", "1") != "0":
-        k_ = deep_state["k"]
-        eng.vit_take()
-        prompts_ = prompts_of(k_ % n_sets)
-        group_ = [(k_ % n_groups) * B + i for i in range(B)]
-        eng.slots_prefill(group_, np.concatenate(prompts_), [len(p_) for p_ in prompts_], [a.max_new_tokens] * B)
-        for s_, p_ in zip(group_, prompts_):
-            deep_state["plen"][s_] = len(p_)
-        fin_, lens_ = eng.slots_poll()
-        eng.synchronize(); torch.cuda.synchronize()      # nothing else is queued: no tower, no prefill
-        live_ = [s_ for s_ in range(len(fin_)) if fin_[s_] == 0]
-        n_alone = 64
-        assert all(lens_[s_] + n_alone < a.max_new_tokens for s_ in live_), "a row would finish inside the decode-alone measurement"
-        ta = time.perf_counter()
-        eng.slots_decode(n_alone)
-        eng.slots_poll()
-        ms_alone = (time.perf_counter() - ta) * 1e3 / n_alone
-        kv_tok_ = cfg.num_hidden_layers * cfg.num_key_value_heads * 128 * 2 * 2
-        ctx0 = [deep_state["plen"][s_] + int(lens_[s_]) for s_ in live_]       # tokens in the KV cache of each row before the first of the n_alone steps
-        bytes_alone = W + kv_tok_ * sum(c_ + (n_alone - 1) / 2.0 + 1 for c_ in ctx0)     # mean over the steps: every weight byte once + the KV read
-        dec_alone_rows = {"bound": "hbm", "achieved": bytes_alone / (ms_alone * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "rows": len(live_),
-                          "ms_per_step": ms_alone, "steps": n_alone, "mean_context": float(np.mean(ctx0)) + n_alone / 2.0, "algorithmic_bytes_per_step": bytes_alone,
-                          "cus": 256, "note": "the decode step of the timed region (every slot group holding rows) replayed alone on the whole chip after the timed region: "
-                                              "no tower, no prefill; wall time of %d hipGraph replays, host-synchronised on both sides" % n_alone}
-        dec_alone_rows["frac"] = dec_alone_rows["achieved"] / dec_alone_rows["peak"]
+        try:                                         # an optional extra: whatever goes wrong here must not cost the run its line
+            k_ = deep_state["k"]
+            eng.vit_take()
+            prompts_ = prompts_of(k_ % n_sets)
+            group_ = [(k_ % n_groups) * B + i for i in range(B)]
+            eng.slots_prefill(group_, np.concatenate(prompts_), [len(p_) for p_ in prompts_], [a.max_new_tokens] * B)
+            for s_, p_ in zip(group_, prompts_):
+                deep_state["plen"][s_] = len(p_)
+            fin_, lens_ = eng.slots_poll()
+            eng.synchronize(); torch.cuda.synchronize()      # nothing else is queued: no tower, no prefill
+            live_ = [s_ for s_ in range(len(fin_)) if fin_[s_] == 0]
+            n_alone = min([64] + [a.max_new_tokens - 1 - int(lens_[s_]) for s_ in live_])      # no row may finish inside the measurement
+            ta = time.perf_counter()
+            if n_alone >= 8:
+                eng.slots_decode(n_alone)
+                eng.slots_poll()
+            ms_alone = (time.perf_counter() - ta) * 1e3 / max(1, n_alone)
+            kv_tok_ = cfg.num_hidden_layers * cfg.num_key_value_heads * 128 * 2 * 2
+            ctx0 = [deep_state["plen"][s_] + int(lens_[s_]) for s_ in live_]       # tokens in the KV cache of each row before the first of the n_alone steps
+            bytes_alone = W + kv_tok_ * sum(c_ + (n_alone - 1) / 2.0 + 1 for c_ in ctx0)     # mean over the steps: every weight byte once + the KV read
+            dec_alone_rows = {"bound": "hbm", "achieved": bytes_alone / (ms_alone * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "rows": len(live_),
+                              "ms_per_step": ms_alone, "steps": n_alone, "mean_context": float(np.mean(ctx0)) + n_alone / 2.0, "algorithmic_bytes_per_step": bytes_alone,
+                              "cus": 256, "note": "the decode step of the timed region (every slot group holding rows) replayed alone on the whole chip after the timed region: "
+                                                  "no tower, no prefill; wall time of %d hipGraph replays, host-synchronised on both sides" % n_alone}
+            dec_alone_rows["frac"] = dec_alone_rows["achieved"] / dec_alone_rows["peak"]
+            if n_alone < 8:                              # short generations (--max-new-tokens below the pipeline's depth): nothing to replay
+                dec_alone_rows = None
+        except Exception as exc:
+            dec_alone_rows = None
+            print(f"bench.py: decode-alone measurement skipped: {exc!r}", file=sys.stderr, flush=True)
     # ---- parity of what was timed: every pipelined step (CU-masked side stream, half-chip decode plan, deferred tower)
     # decoded the same pages with the same prompts as the strictly sequential batch this run started with — the tokens must be
     # identical bit for bit, on every rank, or the run fails.
