@@ -132,10 +132,10 @@ constexpr int ROPE_HPB = 4;
 __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const bf16_t* __restrict__ qkv, const float2* __restrict__ cs,
                                                              const Tile64* __restrict__ tiles, bf16_t* __restrict__ q,
                                                              bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
-                                                             int64_t T, int64_t Tpad, int Hq, int Hkv) {
+                                                             int64_t T, int64_t Tpad, int Hq, int Hkv, int slot0) {
     __shared__ __attribute__((aligned(16))) bf16_t lds[64 * 136];
     const Tile64 tl = tiles[blockIdx.x];
-    const int slot = blockIdx.y;
+    const int slot = blockIdx.y + slot0;                          // slot0 > 0: the V^T slots only (q / k were written by the qkv GEMM's rope epilogue)
     const int ld = (Hq + 2 * Hkv) * 128;
     const int tid = threadIdx.x;
     const int n_groups = (Hq + Hkv + ROPE_HPB - 1) / ROPE_HPB;
@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const bf16_t* __res
                 for (int e = 0; e < 4; ++e) {
                     float2 c0 = cc[2 * e], c1 = cc[2 * e + 1];
                     float a0 = lo_bf(xl[e]), a1 = hi_bf(xl[e]), b0 = lo_bf(xh[e]), b1 = hi_bf(xh[e]);
-                    // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1)
-                    ol[e] = pack_bf2(a0 * c0.x - b0 * c0.y, a1 * c1.x - b1 * c1.y);
-                    oh[e] = pack_bf2(b0 * c0.x + a0 * c0.y, b1 * c1.x + a1 * c1.y);
+                    // q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1).  The fma contractions are written out (they are the ones hipcc chose for
+                    // `a*c - b*s` / `b*c + a*s` in rounds 1-5, so no bit moved): the qkv GEMM's rope epilogue (gemm.hip: w4_epilogue_qkrope) repeats them
+                    // and tests/test_kernels_gpu.py holds the two paths to the same bits
+                    ol[e] = pack_bf2(__builtin_fmaf(a0, c0.x, -(b0 * c0.y)), __builtin_fmaf(a1, c1.x, -(b1 * c1.y)));
+                    oh[e] = pack_bf2(__builtin_fmaf(a0, c0.y, b0 * c0.x), __builtin_fmaf(b1, c1.x, a1 * c1.y));
                 }
                 bf16_t* d = dst + t * 128 + c * 8;
                 *reinterpret_cast<u32x4*>(d) = ol;
@@ -261,9 +263,11 @@ hipError_t launch_rope_table(hipStream_t s, const int32_t* pos, const float* inv
 }
 
 hipError_t launch_qkv_rope_split(hipStream_t s, const bf16_t* qkv, const float2* cs, const Tile64* tiles, int n_tiles,
-                                 bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv) {
+                                 bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv, bool v_only) {
     if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(n_tiles, (Hq + Hkv + ROPE_HPB - 1) / ROPE_HPB + Hkv), dim3(256), 0, s, qkv, cs, tiles, q, k, vt, T, Tpad, Hq, Hkv);
+    const int n_groups = (Hq + Hkv + ROPE_HPB - 1) / ROPE_HPB;
+    if (v_only) hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(n_tiles, Hkv), dim3(256), 0, s, qkv, cs, tiles, q, k, vt, T, Tpad, Hq, Hkv, n_groups);
+    else hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(n_tiles, n_groups + Hkv), dim3(256), 0, s, qkv, cs, tiles, q, k, vt, T, Tpad, Hq, Hkv, 0);
     return hipGetLastError();
 }
 

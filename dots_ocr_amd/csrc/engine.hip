@@ -338,6 +338,25 @@ int vdense(DotsEngine* e, const bf16_t* A, const bf16_t* W, const uint8_t* W8, c
     return dense_on(e, e->vs, e->act_q_v, e->act_s_v, A, W, W8, wscale, bias, R, C, M, N, K, ldc, epi);
 }
 
+// qkv projection + rope + head-major split of a prefill pass (ViT block / LM layer).  bf16 weights on the one-wave-per-SIMD GEMM: the q / k heads
+// leave the GEMM rotated and head-major (launch_gemm_qk_rope), the split kernel only transposes v; anything else: the two kernels of rounds 1-5.
+// Same bits either way (tests/test_kernels_gpu.py).  `st` / scratch as dense_on.
+int qkv_rope_on(DotsEngine* e, hipStream_t st, uint8_t* aq, float* as, const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* wscale, const bf16_t* bias,
+                bf16_t* qkv, const float2* cs, const Tile64* tiles, int n_tiles, bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int K, int Hq, int Hkv) {
+    const int N = (Hq + 2 * Hkv) * 128;
+    if (!W8 && !wscale) {
+        const hipError_t r = launch_gemm_qk_rope(st, A, W, bias, qkv, T, N, K, K, N, cs, q, k, Hq, Hkv);
+        if (r == hipSuccess) {
+            CK(launch_qkv_rope_split(st, qkv, cs, tiles, n_tiles, q, k, vt, T, Tpad, Hq, Hkv, true));
+            return DOTS_OK;
+        }
+        if (r != hipErrorNotSupported) CK(r);
+    }
+    RET(dense_on(e, st, aq, as, A, W, W8, wscale, bias, nullptr, qkv, T, N, K, N, EPI_NONE));
+    CK(launch_qkv_rope_split(st, qkv, cs, tiles, n_tiles, q, k, vt, T, Tpad, Hq, Hkv));
+    return DOTS_OK;
+}
+
 // decode copy of a (quantised) row-major matrix: bf16 fragments, or e4m3 fragments in fp8 mode
 int decode_copy(DotsEngine* e, const bf16_t* W, void** out, int64_t rows, int K, int rot_rows) {
     const size_t elems = (size_t)((rows + 15) / 16 * 16) * K;
@@ -751,8 +770,8 @@ int vit_forward(DotsEngine* e, const float* pix_dev, int64_t N, const int64_t* g
             e->vs = s = e->s_vit_full;
         }
         CK(launch_rmsnorm(s, e->v_x, L.norm1, e->v_xn, N, E, c.v_rms_eps));
-        RET(vdense(e, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, nullptr, e->v_qkv, N, 3 * E, E, 3 * E, EPI_NONE));
-        CK(launch_qkv_rope_split(s, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt, N, Tpad, Hh, Hh));
+        RET(qkv_rope_on(e, s, e->act_q_v, e->act_s_v, e->v_xn, L.qkv_w, L.qkv_8, L.qkv_s, L.qkv_b, e->v_qkv, e->v_cs, e->v_tiles, (int)e->h_tiles.size(), e->v_q, e->v_k, e->v_vt,
+                        N, Tpad, E, Hh, Hh));
         CK(attn_event(e, 2 * i));
         CK(launch_flash_attn(s, e->v_q, e->v_k, e->v_vt, e->v_att, e->v_qblocks, (int)e->h_qblocks.size(), N, Tpad, Hh, Hh, 0, scale, &xcd_plan));
         CK(attn_event(e, 2 * i + 1));
@@ -1026,8 +1045,7 @@ int prefill(DotsEngine* e, const int32_t* ids, const int32_t* lens, int B, const
         const LLayer& Lw = e->ll[i];
         bf16_t* pool_l = e->pool + e->pool_layer_elems * i;
         CK(launch_rmsnorm(s, e->p_x, Lw.ln1, e->p_xn, T, H, c.rms_norm_eps));
-        RET(dense(e, e->p_xn, Lw.qkv_w, Lw.qkv_8, Lw.qkv_s, Lw.qkv_b, nullptr, e->p_qkv, T, NQKV, H, NQKV, EPI_NONE));
-        CK(launch_qkv_rope_split(s, e->p_qkv, e->p_cs, e->p_tiles, n_tiles, e->p_q, e->p_k, e->p_vt, T, Tpad, Hq, Hkv));
+        RET(qkv_rope_on(e, s, e->act_q, e->act_s, e->p_xn, Lw.qkv_w, Lw.qkv_8, Lw.qkv_s, Lw.qkv_b, e->p_qkv, e->p_cs, e->p_tiles, n_tiles, e->p_q, e->p_k, e->p_vt, T, Tpad, H, Hq, Hkv));
         CK(launch_kv_to_pages(s, e->p_k, e->p_qkv, e->p_tiles, n_tiles, e->block_table, e->max_pages, pool_l, T, Hq, Hkv));
         CK(launch_flash_attn(s, e->p_q, e->p_k, e->p_vt, e->p_att, e->p_qblocks, (int)e->hp_qblocks.size(), T, Tpad, Hq, Hkv, 1, scale));
         RET(dense(e, e->p_att, Lw.o_w, Lw.o_8, Lw.o_s, nullptr, e->p_x, e->p_x, T, H, Nq, H, EPI_RESIDUAL));
@@ -1959,6 +1977,48 @@ int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv, void* q, void* k, voi
     hipError_t r = launch_qkv_rope_split(e->stream, (const bf16_t*)qkv, cs, dt, (int)tiles.size(), (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, Tpad, Hq, Hkv);
     hipStreamSynchronize(e->stream);
     e->release(dt); e->release(dq); e->release(dpos); e->release(cs); e->release(freq);
+    CK(r);
+    return DOTS_OK;
+}
+
+// The qkv projection of a prefill pass + rope + head-major split, either as the engine's fused path (fused != 0: the GEMM's rope epilogue writes q / k,
+// the split kernel only transposes v) or as the two kernels of rounds 1-5 — the test holds the two to the same bits.  fused != 0 fails with
+// DOTS_E_INVALID when the process's GEMM plan / the shape has no fused kernel.
+int dots_op_qkv_proj_rope(DotsEngine* e, const void* x, const void* w, const void* bias, void* qkv_ws, void* q, void* k, void* vt, const int32_t* cu, int n_seq,
+                          const int32_t* pos_host, int K, int Hq, int Hkv, int rope2d, float theta, int fused) {
+    if (!e || !x || !w || !qkv_ws || !q || !k || !vt || !cu || n_seq < 1 || !pos_host) return DOTS_E_INVALID;
+    CK(hipSetDevice(e->device));
+    std::vector<Tile64> tiles;
+    std::vector<QBlock> qb;
+    Tile64* dt = nullptr;
+    QBlock* dq = nullptr;
+    int64_t Tpad = 0;
+    RET(upload_lists(e, cu, n_seq, Hq, tiles, qb, &dt, &dq, &Tpad));
+    const int64_t T = cu[n_seq];
+    const int N = (Hq + 2 * Hkv) * 128;
+    int32_t* dpos = nullptr;
+    float2* cs = nullptr;
+    float* freq = nullptr;
+    const int nf = rope2d ? 32 : 64;
+    std::vector<float> f(nf);
+    for (int i = 0; i < nf; ++i) f[i] = 1.0f / powf(theta, (float)(2 * i) / (rope2d ? 64.0f : 128.0f));
+    CK(e->alloc(&dpos, (size_t)T * (rope2d ? 2 : 1)));
+    CK(e->alloc(&cs, (size_t)T * 64));
+    CK(e->alloc(&freq, (size_t)nf));
+    CK(hipMemcpyAsync(dpos, pos_host, (size_t)T * (rope2d ? 2 : 1) * 4, hipMemcpyHostToDevice, e->stream));
+    CK(hipMemcpyAsync(freq, f.data(), nf * 4, hipMemcpyHostToDevice, e->stream));
+    CK(launch_rope_table(e->stream, dpos, freq, cs, T, rope2d));
+    hipError_t r;
+    if (fused) {
+        r = launch_gemm_qk_rope(e->stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, (bf16_t*)qkv_ws, T, N, K, K, N, cs, (bf16_t*)q, (bf16_t*)k, Hq, Hkv);
+        if (r == hipSuccess) r = launch_qkv_rope_split(e->stream, (const bf16_t*)qkv_ws, cs, dt, (int)tiles.size(), (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, Tpad, Hq, Hkv, true);
+    } else {
+        r = launch_gemm(e->stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, nullptr, qkv_ws, T, N, K, K, N, EPI_NONE);
+        if (r == hipSuccess) r = launch_qkv_rope_split(e->stream, (const bf16_t*)qkv_ws, cs, dt, (int)tiles.size(), (bf16_t*)q, (bf16_t*)k, (bf16_t*)vt, T, Tpad, Hq, Hkv);
+    }
+    hipStreamSynchronize(e->stream);
+    e->release(dt); e->release(dq); e->release(dpos); e->release(cs); e->release(freq);
+    if (r == hipErrorNotSupported) { (void)hipGetLastError(); return e->fail(DOTS_E_INVALID, "no fused qkv + rope kernel for this shape / GEMM plan"); }
     CK(r);
     return DOTS_OK;
 }

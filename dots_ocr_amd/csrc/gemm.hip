@@ -698,14 +698,123 @@ DEVI void w4_epilogue_lds(const f32x16 (&acc)[4][4], const W4Cols& cc, bool has_
 #undef W4_PUT
 }
 
+// ---- EPI_QKROPE (round 6): the q / k heads of a fused qkv projection leave the GEMM rotated and head-major.  A wave tile is 128 rows x ONE head
+// (128 columns): the transposition image already holds a token's whole head row, so a lane reads its own 8 columns AND the 8 columns 64 further
+// (d < 64) or 64 back (d >= 64) — slot ^ 16: the same banks as its own slots, the same conflict-free swizzle — rounds both to bf16 exactly as the
+// unfused GEMM would have stored them, and applies qkv_rope_split_kernel's arithmetic bit for bit:
+//     d < 64 : x[d] cos_j - x[d + 64] sin_j        d >= 64 : x[d] cos_j + x[d - 64] sin_j        (j = d & 63; the same two fma contractions)
+// (cos, sin)(t, j) come from the engine's fp32 table, 64 B per lane and row.  One wave per SIMD hides nothing, so the table rows are requested
+// A QUARTER BLOCK AHEAD (8 rows: 8 x 16 B per lane; half a block ahead spilled) and a quarter block's 8 ds_read_b128 are issued together; image writes as w4_epilogue_lds.
+DEVI void w4_load_cols_rope(W4Cols& cc, const bf16_t* __restrict__ bias, const float* __restrict__ colscale, int nw0, int l) {
+    const int gcol = (l & 15) * 8, pcol = gcol ^ 64;
+    u32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    f32x4 s00 = {1.f, 1.f, 1.f, 1.f}, s01 = s00, s10 = s00, s11 = s00;
+    if (bias) {
+        b0 = *reinterpret_cast<const u32x4*>(bias + nw0 + gcol);
+        b1 = *reinterpret_cast<const u32x4*>(bias + nw0 + pcol);
+    }
+    if (colscale) {
+        s00 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol);
+        s01 = *reinterpret_cast<const f32x4*>(colscale + nw0 + gcol + 4);
+        s10 = *reinterpret_cast<const f32x4*>(colscale + nw0 + pcol);
+        s11 = *reinterpret_cast<const f32x4*>(colscale + nw0 + pcol + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cc.sc0[e] = s00[e]; cc.sc0[4 + e] = s01[e]; cc.sc1[e] = s10[e]; cc.sc1[4 + e] = s11[e];
+        cc.bi0[2 * e] = lo_bf(b0[e]); cc.bi0[2 * e + 1] = hi_bf(b0[e]);
+        cc.bi1[2 * e] = lo_bf(b1[e]); cc.bi1[2 * e + 1] = hi_bf(b1[e]);
+    }
+}
+
+template <bool FULL>
+DEVI void w4_epilogue_qkrope(const f32x16 (&acc)[4][4], const W4Cols& cc, bool has_cols, const float2* __restrict__ cs, bf16_t* __restrict__ dst,
+                             int M, int mw0, int l, char* stage2) {
+    const int hi = l >> 5, l31 = l & 31;
+    const int rrow = l >> 4, gcol = (l & 15) * 8;
+    const bool lo_half = (l & 8) == 0;                            // d < 64
+    const float2* const tab = cs + (gcol & 63);
+    auto swz = [](int row) { return ((row & 15) << 1) ^ (row & 1) ^ ((row & 2) << 2); };
+    const int wslot = swz(l31);
+    char* const wrow = stage2 + l31 * 512;
+#define W4_PUT(FM, IMG)                                                                                                   \
+    _Pragma("unroll") for (int fn = 0; fn < 4; ++fn) _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                     \
+        const f32x4 v = {acc[fn][FM][4 * rq], acc[fn][FM][4 * rq + 1], acc[fn][FM][4 * rq + 2], acc[fn][FM][4 * rq + 3]};   \
+        *reinterpret_cast<f32x4*>(wrow + (IMG) * 16384 + (((fn * 8 + rq * 2 + hi) ^ wslot) << 4)) = v;                      \
+    }
+    f32x4 tb[2][2][4];                                            // (cos, sin) of two quarter blocks: [quarter][row iteration][4 x {c0 s0 c1 s1}]
+    auto load_t = [&](int qb, f32x4 (&d)[2][4]) {                 // quarter block qb (0-15): rows mw0 + 8 qb + 4 it + rrow
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = FULL ? mw0 + qb * 8 + it * 4 + rrow : min(mw0 + qb * 8 + it * 4 + rrow, M - 1);
+            const f32x4* tp = reinterpret_cast<const f32x4*>(tab + (size_t)m * 64);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[it][c] = tp[c];
+        }
+    };
+    load_t(0, tb[0]);
+    W4_PUT(0, 0)
+#pragma unroll
+    for (int qb = 0; qb < 16; ++qb) {
+        const int fm = qb >> 2;
+        if (qb + 1 < 16) load_t(qb + 1, tb[(qb + 1) & 1]);
+        if ((qb & 3) == 0 && fm + 1 < 4) {
+            if (fm == 0) { W4_PUT(1, 1) } else if (fm == 1) { W4_PUT(2, 0) } else { W4_PUT(3, 1) }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* img = stage2 + (fm & 1) * 16384;
+        f32x4 a[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = (qb & 3) * 8 + it * 4 + rrow;
+            const int sw = swz(row);
+            const char* rp = img + row * 512;
+            const int s0 = gcol >> 2;
+            a[it][0] = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ sw) << 4));
+            a[it][1] = *reinterpret_cast<const f32x4*>(rp + (((s0 + 1) ^ sw) << 4));
+            a[it][2] = *reinterpret_cast<const f32x4*>(rp + ((s0 ^ 16 ^ sw) << 4));
+            a[it][3] = *reinterpret_cast<const f32x4*>(rp + (((s0 + 1) ^ 16 ^ sw) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = mw0 + qb * 8 + it * 4 + rrow;
+            float o[8] = {a[it][0][0], a[it][0][1], a[it][0][2], a[it][0][3], a[it][1][0], a[it][1][1], a[it][1][2], a[it][1][3]};
+            float u[8] = {a[it][2][0], a[it][2][1], a[it][2][2], a[it][2][3], a[it][3][0], a[it][3][1], a[it][3][2], a[it][3][3]};
+            if (has_cols) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = o[e] * cc.sc0[e] + cc.bi0[e]; u[e] = u[e] * cc.sc1[e] + cc.bi1[e]; }
+            }
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // what the unfused GEMM stores and the split kernel reads back: ONE rounding to bf16 before the rotation
+                const uint32_t ow = pack_bf2(o[2 * e], o[2 * e + 1]), uw = pack_bf2(u[2 * e], u[2 * e + 1]);
+                const float x0 = lo_bf(ow), x1 = hi_bf(ow), y0 = lo_bf(uw), y1 = hi_bf(uw);
+                const f32x4 t4 = tb[qb & 1][it][e];               // {cos j, sin j, cos j+1, sin j+1}, j = (gcol & 63) + 2 e
+                // qkv_rope_split_kernel's contractions (elementwise.hip writes them out):  d < 64: fma(own, cos, -(partner sin));  d >= 64, even d:
+                // fma(partner, sin, own cos), odd d: fma(own, cos, partner sin).  tests/test_kernels_gpu.py holds 25 M elements to the split kernel's bits.
+                const float f0 = lo_half ? x0 : y0, g0 = lo_half ? t4[0] : t4[1], m0 = lo_half ? y0 : x0, n0_ = lo_half ? t4[1] : t4[0];
+                const float p0 = m0 * n0_, p1 = y1 * t4[3];
+                const float r0 = __builtin_fmaf(f0, g0, lo_half ? -p0 : p0), r1 = __builtin_fmaf(x1, t4[2], lo_half ? -p1 : p1);
+                pk[e] = pack_bf2(r0, r1);
+            }
+            if (FULL || m < M) *reinterpret_cast<u32x4*>(dst + (size_t)m * 128 + gcol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef W4_PUT
+}
+
 template <int... I, class F> DEVI void gemm_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> DEVI void gemm_static_for(F&& f) { gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
+DEVI void gemm_bf16_w4_body(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
-    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m) {
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m, const QkRope& rope) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
+    (void)rope;
 
     const int tid = threadIdx.x;
     const int l = tid & 63;
@@ -758,7 +867,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pw0 = wall_clock64();
 #endif
     W4Cols cols;                                                 // the epilogue's column constants: their latency hides behind the main loop
-    if constexpr (EPI != EPI_F32) w4_load_cols<EPI == EPI_SWIGLU>(cols, bias, colscale, n0 + wn * 128, l);
+    if constexpr (EPI == EPI_QKROPE) w4_load_cols_rope(cols, bias, colscale, n0 + wn * 128, l);
+    else if constexpr (EPI != EPI_F32) w4_load_cols<EPI == EPI_SWIGLU>(cols, bias, colscale, n0 + wn * 128, l);
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -862,7 +972,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
         gemm_epilogue_lds<EPI, 4>(acc, bias, colscale, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 16384);
     }
 #else
-    if constexpr (EPI == EPI_F32) {
+    if constexpr (EPI == EPI_QKROPE) {
+        const int head = (n0 + wn * 128) >> 7;                    // wave-uniform: a wave tile is one head
+        const bool full = m0 + wm * 128 + 128 <= M, has_cols = bias != nullptr || colscale != nullptr;
+        if (head < rope.n_rope_heads) {
+            bf16_t* dst = head < rope.Hq ? rope.q + (size_t)head * rope.T * 128 : rope.k + (size_t)(head - rope.Hq) * rope.T * 128;
+            if (full) w4_epilogue_qkrope<true>(acc, cols, has_cols, rope.cs, dst, M, m0 + wm * 128, l, smem2 + w * 32768);
+            else w4_epilogue_qkrope<false>(acc, cols, has_cols, rope.cs, dst, M, m0 + wm * 128, l, smem2 + w * 32768);
+        } else if (full) {                                        // the v heads: stored as EPI_NONE stores them
+            w4_epilogue_lds<EPI_NONE, true>(acc, cols, has_cols, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 32768);
+        } else {
+            w4_epilogue_lds<EPI_NONE, false>(acc, cols, has_cols, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 32768);
+        }
+    } else if constexpr (EPI == EPI_F32) {
         gemm_epilogue<EPI, 4, 4>(acc, bias, colscale, R, Cout, M, ldc, n0 + wn * 128, m0 + wm * 128, l31, hi);
     } else if (m0 + wm * 128 + 128 <= M) {                       // wave-uniform
         w4_epilogue_lds<EPI, true>(acc, cols, bias != nullptr || colscale != nullptr, R, reinterpret_cast<bf16_t*>(Cout), M, ldc, n0 + wn * 128, m0 + wm * 128, l, smem2 + w * 32768);
@@ -878,6 +1000,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
         printf("W4_PROF epi %d N %d K %d blk %d: prologue %llu cyc / %.2f us, main loop %llu cyc / %.2f us (%.0f cyc per K tile), epilogue + drain %llu cyc / %.2f us; issue %llu drain %llu\n", EPI, N, K,
                (int)blockIdx.x, pt1 - pt0, (pw1 - pw0) * 0.01, pt2 - pt1, (pw2 - pw1) * 0.01, (double)(pt2 - pt1) / nt, pt3 - pt2, (pw3 - pw2) * 0.01, pt2b - pt2, pt3 - pt2b);
 #endif
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+    const float* __restrict__ colscale, const bf16_t* R, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m) {
+    gemm_bf16_w4_body<EPI>(A, W, bias, colscale, R, Cout, M, N, K, lda, ldc, m_tiles, n_tiles, group_m, QkRope{});
+}
+// the same kernel with the rope epilogue on its q / k head tiles (launch_gemm_qk_rope)
+__global__ __launch_bounds__(256) void gemm_bf16_w4_qkrope_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
+    const float* __restrict__ colscale, void* Cout, int M, int N, int K, int lda, int ldc, int m_tiles, int n_tiles, int group_m, QkRope rope) {
+    gemm_bf16_w4_body<EPI_QKROPE>(A, W, bias, colscale, nullptr, Cout, M, N, K, lda, ldc, m_tiles, n_tiles, group_m, rope);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1097,6 +1232,31 @@ hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_qk_rope(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, bf16_t* qkv, int64_t M, int N, int K, int lda, int ldc,
+                               const float2* cs, bf16_t* q, bf16_t* k, int Hq, int Hkv) {
+    static const bool off = getenv("DOTS_OCR_QK_FUSE") && atoi(getenv("DOTS_OCR_QK_FUSE")) == 0;       // A/B switch
+    static const bool lockstep = getenv("DOTS_OCR_GEMM_LOCKSTEP") != nullptr, force_small = getenv("DOTS_OCR_GEMM_128") != nullptr;
+    if (off || lockstep || force_small || gemm_get_plan() != 1 || N != (Hq + 2 * Hkv) * 128 || N % BN2 != 0 || K % BK != 0 || K / BK < 3 || lda % 8 != 0 || ldc % 8 != 0 ||
+        !cs || !q || !k || M > 0x7fffffff)
+        return hipErrorNotSupported;
+    if (M <= 0) return hipSuccess;
+    static uint32_t configured = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint32_t bit = 1u << (dev & 31);
+    if (!(__atomic_load_n(&configured, __ATOMIC_ACQUIRE) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w4_qkrope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_RING * W4_UNIT);
+        if (e != hipSuccess) return e;
+        __atomic_fetch_or(&configured, bit, __ATOMIC_RELEASE);
+    }
+    const int m_tiles = (int)((M + BM2 - 1) / BM2), n_tiles = N / BN2;
+    const QkRope rope{cs, q, k, (long long)M, Hq, Hq + Hkv};
+    hipLaunchKernelGGL(gemm_bf16_w4_qkrope_kernel, dim3(m_tiles * n_tiles), dim3(256), W4_RING * W4_UNIT, s, A, W, bias, (const float*)nullptr, (void*)qkv, (int)M, N, K,
+                       lda, ldc, m_tiles, n_tiles, raster_group_m(K * 2), rope);
     return hipGetLastError();
 }
 

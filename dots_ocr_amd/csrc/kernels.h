@@ -7,7 +7,7 @@ typedef uint16_t bf16_t;
 
 #define DOTS_MAX_BATCH 64     // sequences per decode step: 4 tiles of 16 rows (decode_layout.h MAX_DECODE_ROWS)
 
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4, EPI_QKROPE = 5 /* launch_gemm_qk_rope only */ };
 
 // ---- gemm.hip
 hipError_t launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* R,
@@ -28,7 +28,15 @@ hipError_t launch_rope_table(hipStream_t s, const int32_t* pos, const float* inv
 // pad0 = first padded position in the V^T buffer.
 struct Tile64 { int32_t tok0, n, pad0, seq, page, _pad; };   // page = tile index inside its sequence
 hipError_t launch_qkv_rope_split(hipStream_t s, const bf16_t* qkv, const float2* cs, const Tile64* tiles, int n_tiles,
-                                 bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv);
+                                 bf16_t* q, bf16_t* k, bf16_t* vt, int64_t T, int64_t Tpad, int Hq, int Hkv, bool v_only = false);
+// ---- gemm.hip: the fused qkv projection of a prefill pass with the rotary embedding in its epilogue (round 6).  C = A W^T (+ bias) as launch_gemm
+// with EPI_NONE, rounded to bf16 as that GEMM would store it, then: columns [0, (Hq + Hkv) * 128) — the q and k heads — are rotated with cs[t]
+// (the arithmetic of qkv_rope_split_kernel, bit for bit) and written head-major into q [Hq][T][128] / k [Hkv][T][128]; the v columns go to
+// qkv [T][ldc] unrotated (launch_qkv_rope_split(.., v_only = true) transposes them).  hipErrorNotSupported when the shape or the process's GEMM
+// plan has no such kernel (the caller then runs launch_gemm + launch_qkv_rope_split).
+struct QkRope { const float2* cs; bf16_t* q; bf16_t* k; long long T; int Hq; int n_rope_heads; };
+hipError_t launch_gemm_qk_rope(hipStream_t s, const bf16_t* A, const bf16_t* W, const bf16_t* bias, bf16_t* qkv, int64_t M, int N, int K, int lda, int ldc,
+                               const float2* cs, bf16_t* q, bf16_t* k, int Hq, int Hkv);
 // x[t] = src[t] >= 0 ? embed[src[t]] : vision[-src[t]-1]
 hipError_t launch_embed_gather(hipStream_t s, const int32_t* src, const bf16_t* embed, const bf16_t* vision, bf16_t* x,
                                int64_t T, int dim);

@@ -104,6 +104,7 @@ def _prototypes(lib):
         "dots_op_flash_attn": (i32, [vp, vp, vp, vp, vp, P(i32), i32, i32, i32, i32, f32]),
         "dots_plan_flash_xcd": (i32, [P(i32), i32, i32, P(i32), P(i32), P(i64)]),
         "dots_op_qkv_rope_split": (i32, [vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, f32]),
+        "dots_op_qkv_proj_rope": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, P(i32), i32, P(i32), i32, i32, i32, i32, f32, i32]),
         "dots_op_dec_qkv": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, f32, f32, i32]),
         "dots_op_decode_attn": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32]),
         "dots_op_dec_proj": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
@@ -127,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "dots_set_next_tokens", "dots_get_last_tokens", "dots_get_stats", "dots_synchronize", "dots_debug_capture_hidden",
     "dots_debug_read_hidden", "dots_dev_alloc",
     "dots_dev_free", "dots_memcpy_h2d", "dots_memcpy_d2h", "dots_op_rmsnorm", "dots_op_layernorm", "dots_op_gemm", "dots_op_quant_fp8", "dots_op_gemm_fp8",
-    "dots_op_flash_attn", "dots_plan_flash_xcd", "dots_op_qkv_rope_split", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
+    "dots_op_flash_attn", "dots_plan_flash_xcd", "dots_op_qkv_rope_split", "dots_op_qkv_proj_rope", "dots_op_dec_qkv", "dots_op_decode_attn", "dots_op_dec_proj", "dots_op_dec_gateup",
     "dots_op_dec_lmhead", "dots_probe_mfma", "dots_probe_grid_barrier", "dots_probe_cu_mask",
 ]
 
@@ -502,6 +503,12 @@ class Engine:
         pos = np.ascontiguousarray(pos, dtype=np.int32)
         self._ck(self.lib.dots_op_qkv_rope_split(self.h, qkv, q, k, vt, _i32p(cu), cu.shape[0] - 1, _i32p(pos), Hq, Hkv,
                                                  int(rope2d), theta), "dots_op_qkv_rope_split")
+
+    def op_qkv_proj_rope(self, x, w, bias, qkv_ws, q, k, vt, cu_seqlens, pos, K, Hq, Hkv, rope2d, theta, fused):
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self._ck(self.lib.dots_op_qkv_proj_rope(self.h, x, w, bias, qkv_ws, q, k, vt, _i32p(cu), cu.shape[0] - 1, _i32p(pos), K, Hq, Hkv,
+                                                int(rope2d), theta, int(fused)), "dots_op_qkv_proj_rope")
 
     # ---- single kernels of the decode step (row-major device tensors; packing happens inside the library)
     def op_dec_qkv(self, h, ln_w, wqkv, bias, ctx_len, block_table, max_pages, pool_layer, q_out, B, H, Hq, Hkv, eps, rope_theta, fp8=False):

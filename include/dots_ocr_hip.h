@@ -277,6 +277,11 @@ int dots_plan_flash_xcd(const int32_t* lens, int n_seq, int Hq, int32_t* base8, 
 int dots_op_qkv_rope_split(DotsEngine* e, const void* qkv_dev, void* q_dev, void* k_dev, void* vt_dev,
                            const int32_t* cu_seqlens_host, int n_seq, const int32_t* pos_host,
                            int Hq, int Hkv, int rope2d, float theta);
+/* x [T, K] bf16 @ w [(Hq+2*Hkv)*128, K]^T (+ bias) -> rope'd head-major q / k and transposed v (the layouts dots_op_flash_attn consumes), as the
+ * prefill passes run it: fused != 0 = the GEMM's rope epilogue + the v transposition, fused == 0 = GEMM, then dots_op_qkv_rope_split's kernel.
+ * Both give the same bits.  qkv_ws: [T, (Hq+2*Hkv)*128] bf16 workspace.  DOTS_E_INVALID if fused != 0 and no fused kernel serves the shape. */
+int dots_op_qkv_proj_rope(DotsEngine* e, const void* x_dev, const void* w_dev, const void* bias_dev, void* qkv_ws_dev, void* q_dev, void* k_dev, void* vt_dev,
+                          const int32_t* cu_seqlens_host, int n_seq, const int32_t* pos_host, int K, int Hq, int Hkv, int rope2d, float theta, int fused);
 /* ---- single kernels of the decode step, at caller-chosen dimensions.  All tensors are device pointers in
  * the ROW-MAJOR layouts of the HF state dict / of a plain [B, features] activation; the MFMA fragment-order packing the
  * decode step uses (csrc/decode_layout.h) is applied inside with the engine's own pack kernels.  B <= 64.

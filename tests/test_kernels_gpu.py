@@ -250,6 +250,44 @@ def test_lm_rope_split_and_causal_gqa_flash_attn(eng, lens):
     _attn_case(eng, lens, 6, 1, True, False, seed=sum(lens) + 1)
 
 
+@pytest.mark.parametrize("lens,Hq,Hkv,K,rope2d,with_bias", [
+    ([300, 212], 12, 12, 1536, True, False),        # the tower's shape: N = 4608, ragged last m-tile (512 = 2 x 256 exactly: full tiles only)
+    ([700, 77, 1], 12, 12, 256, True, False),       # 778 rows: a ragged last m-tile, a one-token sequence
+    ([130, 515], 12, 2, 1536, False, True),         # the LM prefill's shape: N = 2048, qkv bias, 1-D rope
+    ([64], 2, 2, 192, True, True),                  # fewer rows than a wave tile
+    ([4099, 4093], 12, 12, 192, True, False),       # 25 M q / k elements: the rare roundings where a different fma contraction would show
+    ([8191], 12, 2, 192, False, True),
+])
+def test_qkv_gemm_with_the_rope_epilogue_equals_gemm_then_split_bitwise(eng, lens, Hq, Hkv, K, rope2d, with_bias):
+    """Round 6: the q / k heads leave the qkv GEMM rotated and head-major (gemm.hip: w4_epilogue_qkrope), the split kernel only transposes v.
+    The fused pair must give the bits of GEMM -> qkv_rope_split_kernel (dots_op_qkv_proj_rope runs either), which the tests above hold to the oracle."""
+    g = torch.Generator().manual_seed(sum(lens) + K)
+    T, N = sum(lens), (Hq + 2 * Hkv) * 128
+    x = dev(bf(torch.randn(T, K, generator=g)))
+    w = dev(bf(torch.randn(N, K, generator=g) * (1.5 / math.sqrt(K))))
+    b = dev(bf(torch.randn(N, generator=g))) if with_bias else None
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    Tpad = sum((n + 63) // 64 * 64 for n in lens)
+    if rope2d:
+        pos = torch.stack([torch.randint(0, 120, (T,), generator=g), torch.randint(0, 170, (T,), generator=g)], -1).numpy().astype(np.int32)
+        theta = 10000.0
+    else:
+        pos = torch.cat([torch.arange(n) for n in lens]).numpy().astype(np.int32)
+        theta = 1e6
+    outs = []
+    for fused in (0, 1):
+        ws = torch.full((T, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        qd = torch.full((Hq, T, 128), 5.0, dtype=torch.bfloat16, device="cuda")
+        kd = torch.full((Hkv * (T + 64) * 128,), 5.0, dtype=torch.bfloat16, device="cuda")
+        vtd = torch.full((Hkv, 128, Tpad), 7.0, dtype=torch.bfloat16, device="cuda")
+        run(eng, eng.op_qkv_proj_rope, x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, ws.data_ptr(), qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(),
+            cu, pos, K, Hq, Hkv, rope2d, theta, fused)
+        outs.append((qd.view(torch.int16).cpu(), kd.view(torch.int16).cpu(), vtd.view(torch.int16).cpu(), ws[:, (Hq + Hkv) * 128:].contiguous().view(torch.int16).cpu()))
+    for name, a_, b_ in zip(("q", "k", "v^T", "v columns of the workspace"), outs[0], outs[1]):
+        assert torch.equal(a_, b_), f"{name}: the fused path differs from GEMM + split ({int((a_ != b_).sum())} of {a_.numel()} elements)"
+    assert not torch.equal(outs[0][0], torch.full_like(outs[0][0], outs[0][0][0, 0, 0].item())), "q was not written"
+
+
 def test_flash_attn_online_softmax_rescale_branch(eng):
     """A key far above the rest arriving in a LATE tile forces the running-max rescale (guide §5.4 rule 26)."""
     g = torch.Generator().manual_seed(11)
