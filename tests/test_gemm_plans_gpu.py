@@ -20,7 +20,7 @@ def eng():
     from dots_ocr_amd.engine import Engine
     e = Engine(DotsConfig.tiny(), max_batch=2, max_seq_len=256, max_patches=256, max_prefill_tokens=256)
     yield e
-    e.set_gemm_plan(0)
+    e.set_gemm_plan(1)                                # the process-wide default (round 5); a 0 here left every later module of the session on the round-2 kernel
     e.close()
 
 

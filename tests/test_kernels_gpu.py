@@ -261,6 +261,7 @@ def test_lm_rope_split_and_causal_gqa_flash_attn(eng, lens):
 def test_qkv_gemm_with_the_rope_epilogue_equals_gemm_then_split_bitwise(eng, lens, Hq, Hkv, K, rope2d, with_bias):
     """Round 6: the q / k heads leave the qkv GEMM rotated and head-major (gemm.hip: w4_epilogue_qkrope), the split kernel only transposes v.
     The fused pair must give the bits of GEMM -> qkv_rope_split_kernel (dots_op_qkv_proj_rope runs either), which the tests above hold to the oracle."""
+    eng.set_gemm_plan(1)                              # the fused kernel belongs to the one-wave-per-SIMD plan (the process default)
     g = torch.Generator().manual_seed(sum(lens) + K)
     T, N = sum(lens), (Hq + 2 * Hkv) * 128
     x = dev(bf(torch.randn(T, K, generator=g)))
